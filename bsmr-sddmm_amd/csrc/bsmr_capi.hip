@@ -1,0 +1,594 @@
+// C ABI of libbsmr_hip.so (include/bsmr_hip.h): device management, plan
+// construction (RPHM host arrays -> compact device format), kernel launchers and
+// event timing.  See the header for the reference interfaces each entry replaces.
+
+#include "bsmr_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "sddmm_kernels.hpp"
+
+using bsmr::DenseItem;
+using bsmr::SparseItem;
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+struct bsmr_plan {
+    int device = 0;
+    uint32_t M = 0, N = 0, nnz = 0, numPanels = 0;
+
+    // device-resident metadata
+    uint32_t* panelRows = nullptr;   // [numPanels*16] original row per panel row (padding -> a valid row)
+    uint32_t* blockCols = nullptr;   // [numBlocks*16] column per tile column (padding -> column 0)
+    uint64_t* blockMask = nullptr;   // [numBlocks*4]  lane-major occupancy bitmap
+    uint32_t* blockBase = nullptr;   // [numBlocks*4]  offset of each mask word's first destination
+    uint32_t* dstIndex = nullptr;    // [numDenseEntries] CSR index, accumulator order
+    DenseItem* denseItems = nullptr;
+    uint32_t* entryCol = nullptr;    // [numSparseEntries]
+    uint32_t* entryDst = nullptr;    // [numSparseEntries] CSR index
+    uint8_t* entryRow = nullptr;     // [numSparseEntries] row inside the panel
+    SparseItem* sparseItems = nullptr;
+
+    uint64_t numBlocks = 0, numDenseEntries = 0, numSparseEntries = 0;
+    uint32_t numDenseItems = 0, numSparseItems = 0;
+    uint64_t indexBytes = 0;
+
+    // operand workspace (16-bit copies of A and B), grown on demand
+    uint16_t* A16 = nullptr;
+    uint16_t* B16 = nullptr;
+    uint32_t reservedK = 0;
+
+    int sparseLpe = 8;
+};
+
+namespace {
+
+thread_local std::string g_lastHipError;
+
+inline bool hipOk(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    g_lastHipError = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return false;
+}
+
+#define BSMR_HIP(call)                                   \
+    do {                                                 \
+        if (!hipOk((call), #call)) return BSMR_ERR_HIP;  \
+    } while (0)
+
+int useDevice(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        g_lastHipError = "no HIP device";
+        return BSMR_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return BSMR_ERR_NO_DEVICE;
+    BSMR_HIP(hipSetDevice(device));
+    return BSMR_OK;
+}
+
+template <typename T>
+int upload(T*& dst, const std::vector<T>& src, uint64_t& bytes) {
+    dst = nullptr;
+    if (src.empty()) return BSMR_OK;
+    const size_t n = src.size() * sizeof(T);
+    if (!hipOk(hipMalloc(reinterpret_cast<void**>(&dst), n), "hipMalloc(plan)")) return BSMR_ERR_OOM;
+    BSMR_HIP(hipMemcpy(dst, src.data(), n, hipMemcpyHostToDevice));
+    bytes += n;
+    return BSMR_OK;
+}
+
+int envInt(const char* name, int fallback) {
+    const char* v = std::getenv(name);
+    if (!v || !*v) return fallback;
+    return std::atoi(v);
+}
+
+void freePlanDevice(bsmr_plan* p) {
+    void* ptrs[] = {p->panelRows, p->blockCols, p->blockMask, p->blockBase, p->dstIndex,
+                    p->denseItems, p->entryCol, p->entryDst, p->entryRow, p->sparseItems,
+                    p->A16, p->B16};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+}
+
+inline uint32_t gridFor(uint32_t workgroups) { return (workgroups + 7u) & ~7u; }  // multiple of 8 XCDs
+
+// --- launchers -------------------------------------------------------------
+template <int MODE>
+int launchConvert(const bsmr_plan* p, uint32_t K, const float* A, const float* B, uint16_t* A16,
+                  uint16_t* B16, hipStream_t s) {
+    const uint64_t nA8 = (uint64_t)p->M * K / 8, nB8 = (uint64_t)p->N * K / 8;
+    const uint64_t total = nA8 + nB8;
+    if (total == 0) return BSMR_OK;
+    const uint64_t wgs = std::min<uint64_t>((total + bsmr::kThreads - 1) / bsmr::kThreads, 256 * 16);
+    hipLaunchKernelGGL((bsmr::convertOperands<MODE>), dim3((unsigned)wgs), dim3(bsmr::kThreads), 0, s, A,
+                       nA8, B, nB8, A16, B16);
+    BSMR_HIP(hipGetLastError());
+    return BSMR_OK;
+}
+
+template <int KS, int MODE>
+void launchDense16KS(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
+                     hipStream_t s) {
+    const uint32_t wgs = gridFor((p->numDenseItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG);
+    hipLaunchKernelGGL((bsmr::denseBlocks16<KS, MODE>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A16, B16,
+                       K, p->panelRows, p->blockCols, p->blockMask, p->blockBase, p->dstIndex,
+                       p->denseItems, p->numDenseItems, P);
+}
+
+template <int MODE>
+int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
+                  hipStream_t s) {
+    if (p->numDenseItems == 0) return BSMR_OK;
+    switch (K) {
+    case 32: launchDense16KS<1, MODE>(p, K, A16, B16, P, s); break;
+    case 64: launchDense16KS<2, MODE>(p, K, A16, B16, P, s); break;
+    case 128: launchDense16KS<4, MODE>(p, K, A16, B16, P, s); break;
+    case 256: launchDense16KS<8, MODE>(p, K, A16, B16, P, s); break;
+    case 512: launchDense16KS<16, MODE>(p, K, A16, B16, P, s); break;
+    default: launchDense16KS<0, MODE>(p, K, A16, B16, P, s); break;
+    }
+    BSMR_HIP(hipGetLastError());
+    return BSMR_OK;
+}
+
+int launchDense32(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P,
+                  hipStream_t s) {
+    if (p->numDenseItems == 0) return BSMR_OK;
+    const uint32_t wgs = gridFor((p->numDenseItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG);
+    hipLaunchKernelGGL(bsmr::denseBlocks32, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, p->panelRows,
+                       p->blockCols, p->blockMask, p->blockBase, p->dstIndex, p->denseItems,
+                       p->numDenseItems, P);
+    BSMR_HIP(hipGetLastError());
+    return BSMR_OK;
+}
+
+template <int LPE>
+int launchSparseLpe(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P,
+                    hipStream_t s) {
+    const size_t lds = (size_t)16 * (K + bsmr::kSparseLdsPad) * sizeof(float);
+    const uint32_t wgs = p->numSparseItems;  // no padding: every workgroup reads its item
+    if (lds <= 64 * 1024) {
+        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, true>), dim3(wgs), dim3(bsmr::kThreads), lds, s, A, B,
+                           K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P);
+    } else {
+        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, false>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B,
+                           K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P);
+    }
+    BSMR_HIP(hipGetLastError());
+    return BSMR_OK;
+}
+
+int launchSparse(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, hipStream_t s) {
+    if (p->numSparseItems == 0) return BSMR_OK;
+    // never more lanes per entry than float4 chunks in a column
+    int lpe = p->sparseLpe;
+    while (lpe > 1 && (uint32_t)lpe > K / 4) lpe >>= 1;
+    switch (lpe) {
+    case 16: return launchSparseLpe<16>(p, K, A, B, P, s);
+    case 4: return launchSparseLpe<4>(p, K, A, B, P, s);
+    default: return launchSparseLpe<8>(p, K, A, B, P, s);
+    }
+}
+
+int checkCall(const bsmr_plan* p, uint32_t K, const void* A, const void* B, const void* P, int mode) {
+    if (!p || !P) return BSMR_ERR_INVALID_ARG;
+    if (!A || !B) return BSMR_ERR_INVALID_ARG;
+    if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
+    if (mode != BSMR_COMPUTE_F16 && mode != BSMR_COMPUTE_BF16 && mode != BSMR_COMPUTE_F32)
+        return BSMR_ERR_INVALID_ARG;
+    return BSMR_OK;
+}
+
+int reserve(bsmr_plan* p, uint32_t K) {
+    if (p->reservedK >= K && p->A16 && p->B16) return BSMR_OK;
+    if (p->A16) (void)hipFree(p->A16);
+    if (p->B16) (void)hipFree(p->B16);
+    p->A16 = p->B16 = nullptr;
+    p->reservedK = 0;
+    const size_t a = std::max<size_t>((size_t)p->M * K * 2, 16), b = std::max<size_t>((size_t)p->N * K * 2, 16);
+    if (!hipOk(hipMalloc(reinterpret_cast<void**>(&p->A16), a), "hipMalloc(A16)")) return BSMR_ERR_OOM;
+    if (!hipOk(hipMalloc(reinterpret_cast<void**>(&p->B16), b), "hipMalloc(B16)")) return BSMR_ERR_OOM;
+    p->reservedK = K;
+    return BSMR_OK;
+}
+
+// which: bit 0 convert, bit 1 dense, bit 2 sparse
+int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, int mode, hipStream_t s,
+              int which) {
+    int st = BSMR_OK;
+    if (mode == BSMR_COMPUTE_F32) {
+        if ((which & 2) && (st = launchDense32(p, K, A, B, P, s)) != BSMR_OK) return st;
+    } else {
+        if (p->numDenseItems) {
+            if (which & 1) {
+                st = mode == BSMR_COMPUTE_F16 ? launchConvert<0>(p, K, A, B, p->A16, p->B16, s)
+                                              : launchConvert<1>(p, K, A, B, p->A16, p->B16, s);
+                if (st != BSMR_OK) return st;
+            }
+            if (which & 2) {
+                st = mode == BSMR_COMPUTE_F16 ? launchDense16<0>(p, K, p->A16, p->B16, P, s)
+                                              : launchDense16<1>(p, K, p->A16, p->B16, P, s);
+                if (st != BSMR_OK) return st;
+            }
+        }
+    }
+    if ((which & 4) && (st = launchSparse(p, K, A, B, P, s)) != BSMR_OK) return st;
+    return BSMR_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// exported functions
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* bsmr_strerror(int status) {
+    switch (status) {
+    case BSMR_OK: return "success";
+    case BSMR_ERR_INVALID_ARG: return "invalid argument";
+    case BSMR_ERR_NO_DEVICE: return "no usable HIP device";
+    case BSMR_ERR_HIP: return "HIP runtime error";
+    case BSMR_ERR_UNSUPPORTED_K: return "K must be a positive multiple of 32";
+    case BSMR_ERR_OOM: return "out of memory";
+    case BSMR_ERR_BAD_PLAN: return "index arrays violate the RPHM invariants";
+    default: return "unknown status";
+    }
+}
+
+const char* bsmr_last_hip_error(void) { return g_lastHipError.c_str(); }
+
+int bsmr_device_count(int* count) {
+    if (!count) return BSMR_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return BSMR_OK;
+}
+
+int bsmr_mem_info(int device, size_t* free_bytes, size_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return BSMR_ERR_INVALID_ARG;
+    const int st = useDevice(device);
+    if (st != BSMR_OK) return st;
+    BSMR_HIP(hipMemGetInfo(free_bytes, total_bytes));
+    return BSMR_OK;
+}
+
+int bsmr_device_name(int device, char* buf, size_t buflen) {
+    if (!buf || buflen == 0) return BSMR_ERR_INVALID_ARG;
+    const int st = useDevice(device);
+    if (st != BSMR_OK) return st;
+    hipDeviceProp_t prop;
+    BSMR_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s (%s)", prop.name, prop.gcnArchName);
+    return BSMR_OK;
+}
+
+int bsmr_dev_alloc(int device, size_t bytes, void** out) {
+    if (!out) return BSMR_ERR_INVALID_ARG;
+    *out = nullptr;
+    const int st = useDevice(device);
+    if (st != BSMR_OK) return st;
+    if (!hipOk(hipMalloc(out, std::max<size_t>(bytes, 16)), "hipMalloc")) return BSMR_ERR_OOM;
+    return BSMR_OK;
+}
+
+int bsmr_dev_free(void* ptr) {
+    if (!ptr) return BSMR_OK;
+    BSMR_HIP(hipFree(ptr));
+    return BSMR_OK;
+}
+
+int bsmr_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return BSMR_OK;
+    if (!dst || !src) return BSMR_ERR_INVALID_ARG;
+    BSMR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return BSMR_OK;
+}
+
+int bsmr_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return BSMR_OK;
+    if (!dst || !src) return BSMR_ERR_INVALID_ARG;
+    BSMR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return BSMR_OK;
+}
+
+int bsmr_dev_memset(void* dst, int value, size_t bytes) {
+    if (bytes == 0) return BSMR_OK;
+    if (!dst) return BSMR_ERR_INVALID_ARG;
+    BSMR_HIP(hipMemset(dst, value, bytes));
+    return BSMR_OK;
+}
+
+int bsmr_device_synchronize(int device) {
+    const int st = useDevice(device);
+    if (st != BSMR_OK) return st;
+    BSMR_HIP(hipDeviceSynchronize());
+    return BSMR_OK;
+}
+
+int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
+    if (!out || !d) return BSMR_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!d->block_offsets || !d->sparse_value_offsets || (!d->reordered_rows && d->num_nonzero_rows))
+        return BSMR_ERR_INVALID_ARG;
+    const uint32_t P = d->num_row_panels;
+    if ((uint64_t)P * 16 < d->num_nonzero_rows || (P && (uint64_t)(P - 1) * 16 >= d->num_nonzero_rows))
+        return BSMR_ERR_BAD_PLAN;
+    const uint64_t numBlocks = d->block_offsets[P];
+    const uint64_t numSparse = d->sparse_value_offsets[P];
+    if (numBlocks && (!d->dense_cols || !d->block_values)) return BSMR_ERR_INVALID_ARG;
+    if (numSparse && (!d->sparse_values || !d->sparse_relative_rows || !d->sparse_col_indices))
+        return BSMR_ERR_INVALID_ARG;
+
+    int st = useDevice(device);
+    if (st != BSMR_OK) return st;
+
+    try {
+        // ---- host-side packing -------------------------------------------
+        std::vector<uint32_t> panelRows((size_t)P * 16);
+        for (size_t i = 0; i < panelRows.size(); ++i) {
+            const uint32_t row = i < d->num_nonzero_rows ? d->reordered_rows[i] : d->reordered_rows[0];
+            if (row >= d->M) return BSMR_ERR_BAD_PLAN;
+            panelRows[i] = row;
+        }
+        for (uint32_t p = 0; p < P; ++p)
+            if (d->block_offsets[p + 1] < d->block_offsets[p] ||
+                d->sparse_value_offsets[p + 1] < d->sparse_value_offsets[p])
+                return BSMR_ERR_BAD_PLAN;
+
+        std::vector<uint32_t> blockCols(numBlocks * 16);
+        for (size_t i = 0; i < blockCols.size(); ++i) {
+            const uint32_t c = d->dense_cols[i];
+            if (c > d->N) return BSMR_ERR_BAD_PLAN;
+            blockCols[i] = c == d->N ? 0u : c;  // padding column: any readable column, its outputs are masked
+        }
+
+        std::vector<uint64_t> blockMask(numBlocks * 4, 0);
+        std::vector<uint32_t> blockBase(numBlocks * 4, 0);
+        std::vector<uint32_t> dstIndex;
+        dstIndex.reserve(d->nnz);
+        for (uint64_t b = 0; b < numBlocks; ++b) {
+            const uint32_t* tile = d->block_values + b * 256;
+            for (uint32_t g = 0; g < 4; ++g) {
+                blockBase[b * 4 + g] = (uint32_t)dstIndex.size();
+                uint64_t word = 0;
+                for (uint32_t c = 0; c < 16; ++c)
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        const uint32_t v = tile[(4 * g + i) * 16 + c];
+                        if (v == 0xFFFFFFFFu) continue;
+                        if (v >= d->nnz) return BSMR_ERR_BAD_PLAN;
+                        word |= 1ull << (4 * c + i);
+                        dstIndex.push_back(v);
+                    }
+                blockMask[b * 4 + g] = word;
+            }
+        }
+
+        std::vector<uint32_t> entryCol(numSparse), entryDst(numSparse);
+        std::vector<uint8_t> entryRow(numSparse);
+        for (uint64_t i = 0; i < numSparse; ++i) {
+            if (d->sparse_col_indices[i] >= d->N || d->sparse_values[i] >= d->nnz ||
+                d->sparse_relative_rows[i] >= 16)
+                return BSMR_ERR_BAD_PLAN;
+            entryCol[i] = d->sparse_col_indices[i];
+            entryDst[i] = d->sparse_values[i];
+            entryRow[i] = (uint8_t)d->sparse_relative_rows[i];
+        }
+        if (dstIndex.size() + numSparse != d->nnz) return BSMR_ERR_BAD_PLAN;
+
+        // ---- work lists ----------------------------------------------------
+        // dense: runs of `chunk` blocks of one panel per wave; small enough that
+        // the chip (256 CUs x 4 SIMDs x several waves) is covered, large enough
+        // that the panel's A fragments are amortised.
+        int chunk = envInt("BSMR_DENSE_CHUNK", 0);
+        if (chunk <= 0) {
+            const uint64_t targetWaves = 256ull * 4 * 6;
+            chunk = (int)std::max<uint64_t>(1, std::min<uint64_t>(16, numBlocks / targetWaves));
+        }
+        std::vector<DenseItem> denseItems;
+        for (uint32_t p = 0; p < P; ++p)
+            for (uint32_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; b += chunk)
+                denseItems.push_back(DenseItem{p, b, std::min<uint32_t>(chunk, d->block_offsets[p + 1] - b), 0});
+
+        const uint32_t perWG = (uint32_t)std::max(32, envInt("BSMR_SPARSE_ENTRIES_PER_WG", 256));
+        std::vector<SparseItem> sparseItems;
+        for (uint32_t p = 0; p < P; ++p)
+            for (uint32_t s = d->sparse_value_offsets[p]; s < d->sparse_value_offsets[p + 1]; s += perWG)
+                sparseItems.push_back(
+                    SparseItem{p, s, std::min<uint32_t>(perWG, d->sparse_value_offsets[p + 1] - s), 0});
+
+        // ---- upload ----------------------------------------------------------
+        bsmr_plan* p = new (std::nothrow) bsmr_plan;
+        if (!p) return BSMR_ERR_OOM;
+        p->device = device;
+        p->M = d->M;
+        p->N = d->N;
+        p->nnz = d->nnz;
+        p->numPanels = P;
+        p->numBlocks = numBlocks;
+        p->numDenseEntries = dstIndex.size();
+        p->numSparseEntries = numSparse;
+        p->numDenseItems = (uint32_t)denseItems.size();
+        p->numSparseItems = (uint32_t)sparseItems.size();
+        p->sparseLpe = envInt("BSMR_SPARSE_LPE", 8);
+        if (p->sparseLpe != 4 && p->sparseLpe != 8 && p->sparseLpe != 16) p->sparseLpe = 8;
+
+        st = upload(p->panelRows, panelRows, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->blockCols, blockCols, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->blockMask, blockMask, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->blockBase, blockBase, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->dstIndex, dstIndex, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->denseItems, denseItems, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->entryCol, entryCol, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->entryDst, entryDst, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->entryRow, entryRow, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->sparseItems, sparseItems, p->indexBytes);
+        if (st != BSMR_OK) {
+            freePlanDevice(p);
+            delete p;
+            return st;
+        }
+        *out = p;
+        return BSMR_OK;
+    } catch (const std::bad_alloc&) {
+        return BSMR_ERR_OOM;
+    } catch (...) {
+        return BSMR_ERR_INVALID_ARG;
+    }
+}
+
+int bsmr_plan_destroy(bsmr_plan* plan) {
+    if (!plan) return BSMR_OK;
+    if (hipSetDevice(plan->device) != hipSuccess) (void)hipGetLastError();
+    freePlanDevice(plan);
+    delete plan;
+    return BSMR_OK;
+}
+
+int bsmr_plan_get_stats(const bsmr_plan* p, bsmr_plan_stats* out) {
+    if (!p || !out) return BSMR_ERR_INVALID_ARG;
+    out->num_row_panels = p->numPanels;
+    out->num_dense_blocks = p->numBlocks;
+    out->num_dense_entries = p->numDenseEntries;
+    out->num_sparse_entries = p->numSparseEntries;
+    out->dense_work_items = p->numDenseItems;
+    out->sparse_work_items = p->numSparseItems;
+    out->device_index_bytes = p->indexBytes;
+    return BSMR_OK;
+}
+
+int bsmr_plan_reserve(bsmr_plan* plan, uint32_t K) {
+    if (!plan) return BSMR_ERR_INVALID_ARG;
+    if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
+    BSMR_HIP(hipSetDevice(plan->device));
+    return reserve(plan, K);
+}
+
+int bsmr_sddmm(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode,
+               void* stream) {
+    int st = checkCall(plan, K, A, B, P, mode);
+    if (st != BSMR_OK) return st;
+    BSMR_HIP(hipSetDevice(plan->device));
+    if (mode != BSMR_COMPUTE_F32 && plan->numDenseItems && (st = reserve(plan, K)) != BSMR_OK) return st;
+    return runPieces(plan, K, A, B, P, mode, static_cast<hipStream_t>(stream), 7);
+}
+
+int bsmr_convert_operands(bsmr_plan* plan, uint32_t K, const float* A, const float* B, void* A16,
+                          void* B16, int mode, void* stream) {
+    if (!plan || !A || !B || !A16 || !B16) return BSMR_ERR_INVALID_ARG;
+    if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
+    if (mode != BSMR_COMPUTE_F16 && mode != BSMR_COMPUTE_BF16) return BSMR_ERR_INVALID_ARG;
+    BSMR_HIP(hipSetDevice(plan->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return mode == BSMR_COMPUTE_F16
+               ? launchConvert<0>(plan, K, A, B, static_cast<uint16_t*>(A16), static_cast<uint16_t*>(B16), s)
+               : launchConvert<1>(plan, K, A, B, static_cast<uint16_t*>(A16), static_cast<uint16_t*>(B16), s);
+}
+
+int bsmr_sddmm_lowp(bsmr_plan* plan, uint32_t K, const void* A16, const void* B16, const float* A,
+                    const float* B, float* P, int mode, void* stream) {
+    if (!plan || !A16 || !B16 || !P) return BSMR_ERR_INVALID_ARG;
+    if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
+    if (mode != BSMR_COMPUTE_F16 && mode != BSMR_COMPUTE_BF16) return BSMR_ERR_INVALID_ARG;
+    if (plan->numSparseItems && (!A || !B)) return BSMR_ERR_INVALID_ARG;  // sparse residue needs fp32 operands
+    BSMR_HIP(hipSetDevice(plan->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int st = mode == BSMR_COMPUTE_F16
+                 ? launchDense16<0>(plan, K, static_cast<const uint16_t*>(A16),
+                                    static_cast<const uint16_t*>(B16), P, s)
+                 : launchDense16<1>(plan, K, static_cast<const uint16_t*>(A16),
+                                    static_cast<const uint16_t*>(B16), P, s);
+    if (st != BSMR_OK) return st;
+    return launchSparse(plan, K, A, B, P, s);
+}
+
+int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode,
+                     void* stream, int warmup, int iters, bsmr_timing* out) {
+    int st = checkCall(plan, K, A, B, P, mode);
+    if (st != BSMR_OK) return st;
+    if (!out || iters <= 0 || warmup < 0) return BSMR_ERR_INVALID_ARG;
+    BSMR_HIP(hipSetDevice(plan->device));
+    if (mode != BSMR_COMPUTE_F32 && plan->numDenseItems && (st = reserve(plan, K)) != BSMR_OK) return st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    BSMR_HIP(hipEventCreate(&e0));
+    if (!hipOk(hipEventCreate(&e1), "hipEventCreate")) {
+        (void)hipEventDestroy(e0);
+        return BSMR_ERR_HIP;
+    }
+    auto timeLoop = [&](int which, float& ms) -> int {
+        hipError_t e = hipEventRecord(e0, s);
+        int rc = BSMR_OK;
+        for (int i = 0; i < iters && rc == BSMR_OK; ++i) rc = runPieces(plan, K, A, B, P, mode, s, which);
+        if (e == hipSuccess) e = hipEventRecord(e1, s);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+        if (!hipOk(e, "event timing")) return BSMR_ERR_HIP;
+        ms = t / iters;
+        return rc;
+    };
+    for (int i = 0; i < warmup && st == BSMR_OK; ++i) st = runPieces(plan, K, A, B, P, mode, s, 7);
+    bsmr_timing t{};
+    if (st == BSMR_OK) st = timeLoop(7, t.total_ms);
+    if (st == BSMR_OK && mode != BSMR_COMPUTE_F32 && plan->numDenseItems) st = timeLoop(1, t.convert_ms);
+    if (st == BSMR_OK && plan->numDenseItems) st = timeLoop(2, t.dense_ms);
+    if (st == BSMR_OK && plan->numSparseItems) st = timeLoop(4, t.sparse_ms);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (st == BSMR_OK) *out = t;
+    return st;
+}
+
+int bsmr_sddmm_host(bsmr_plan* plan, uint32_t K, const float* A_host, const float* B_host, float* P_host,
+                    int mode, int iters, float* ms_per_iter) {
+    int st = checkCall(plan, K, A_host, B_host, P_host, mode);
+    if (st != BSMR_OK) return st;
+    if (iters <= 0) iters = 1;
+    BSMR_HIP(hipSetDevice(plan->device));
+    const size_t aBytes = (size_t)plan->M * K * 4, bBytes = (size_t)plan->N * K * 4, pBytes = (size_t)plan->nnz * 4;
+    float *A = nullptr, *B = nullptr, *P = nullptr;
+    auto cleanup = [&]() {
+        if (A) (void)hipFree(A);
+        if (B) (void)hipFree(B);
+        if (P) (void)hipFree(P);
+    };
+    if (!hipOk(hipMalloc(reinterpret_cast<void**>(&A), std::max<size_t>(aBytes, 16)), "hipMalloc(A)") ||
+        !hipOk(hipMalloc(reinterpret_cast<void**>(&B), std::max<size_t>(bBytes, 16)), "hipMalloc(B)") ||
+        !hipOk(hipMalloc(reinterpret_cast<void**>(&P), std::max<size_t>(pBytes, 16)), "hipMalloc(P)")) {
+        cleanup();
+        return BSMR_ERR_OOM;
+    }
+    if (!hipOk(hipMemcpy(A, A_host, aBytes, hipMemcpyHostToDevice), "h2d A") ||
+        !hipOk(hipMemcpy(B, B_host, bBytes, hipMemcpyHostToDevice), "h2d B") ||
+        !hipOk(hipMemset(P, 0, std::max<size_t>(pBytes, 16)), "memset P")) {
+        cleanup();
+        return BSMR_ERR_HIP;
+    }
+    bsmr_timing t{};
+    st = bsmr_sddmm_timed(plan, K, A, B, P, mode, nullptr, 1, iters, &t);
+    if (st == BSMR_OK && pBytes && !hipOk(hipMemcpy(P_host, P, pBytes, hipMemcpyDeviceToHost), "d2h P"))
+        st = BSMR_ERR_HIP;
+    if (st == BSMR_OK && ms_per_iter) *ms_per_iter = t.total_ms;
+    cleanup();
+    return st;
+}
+
+}  // extern "C"

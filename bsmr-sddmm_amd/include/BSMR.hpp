@@ -1,0 +1,194 @@
+#pragma once
+// Host side of the BSMR pipeline: row clustering at threshold alpha, per-panel
+// column reordering, dense/sparse block split at threshold delta, and the RPHM
+// block format.  Public interface of the reference's include/BSMR.hpp:21-245;
+// the implementation (src/BSMR.cpp, src/rowReordering.cpp, src/colReordering.cpp)
+// is C++17/OpenMP written for this engine.
+//
+// RPHM differs from the reference in ownership only: the reference keeps twelve
+// dev::vector<UIN> (device copies); here the index arrays stay host-visible
+// std::vectors and the device-resident form lives in an opaque bsmr_plan made
+// through the C ABI (include/bsmr_hip.h).
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "Logger.hpp"
+#include "Matrix.hpp"
+
+struct bsmr_plan;
+
+constexpr UIN ROW_PANEL_SIZE = MFMA_M;
+constexpr UIN BLOCK_COL_SIZE = MFMA_N;
+constexpr UIN BLOCK_SIZE = ROW_PANEL_SIZE * BLOCK_COL_SIZE;
+
+// Launch-geometry constants of the reference's kernels (include/sddmmKernel.cuh:11-17).
+// They only feed the reference-compatible work lists / log fields of RPHM and
+// evaluationReordering(); the HIP kernels use their own geometry.
+constexpr int each_thread_block_counts_the_number_Of_dense_blocks = 4;
+constexpr int sddmm_sparse_block_number_of_thread_per_thread_block = 256;
+constexpr int sddmm_sparse_block_each_thread_block_counts_the_number_Of_data =
+    sddmm_sparse_block_number_of_thread_per_thread_block / 2;
+
+class BSMR {
+public:
+    BSMR() = default;
+
+    BSMR(const float similarityThreshold, const float blockDensityThreshold,
+         const sparseMatrix::CSR<float>& matrix, const int numIterations = 1);
+
+    void rowReordering(const float similarityThreshold, const sparseMatrix::CSR<float>& matrix,
+                       const int numIterations = 1);
+
+    void colReordering(const float blockDensityThreshold, const sparseMatrix::CSR<float>& matrix,
+                       const std::vector<UIN>& reorderedRows = std::vector<UIN>(),
+                       const int numIterations = 1);
+
+    int numRowPanels() const { return numRowPanels_; }
+    const std::vector<UIN>& reorderedRows() const { return reorderedRows_; }
+    const std::vector<UIN>& denseCols() const { return denseCols_; }
+    const std::vector<UIN>& denseColOffsets() const { return denseColOffsets_; }
+    const std::vector<UIN>& sparseCols() const { return sparseCols_; }
+    const std::vector<UIN>& sparseColOffsets() const { return sparseColOffsets_; }
+    const std::vector<UIN>& sparseValueOffsets() const { return sparseValueOffsets_; }
+    int numClusters() const { return numClusters_; }
+    float rowReorderingTime() const { return rowReorderingTime_; }
+    float colReorderingTime() const { return colReorderingTime_; }
+    float reorderingTime() const { return rowReorderingTime_ + colReorderingTime_; }
+
+private:
+    int numRowPanels_ = 0;
+    std::vector<UIN> reorderedRows_;
+    std::vector<UIN> denseCols_;
+    std::vector<UIN> denseColOffsets_;
+    std::vector<UIN> sparseCols_;
+    std::vector<UIN> sparseColOffsets_;
+    std::vector<UIN> sparseValueOffsets_;
+    int numClusters_ = 1;
+    float rowReorderingTime_ = 0.0f;
+    float colReorderingTime_ = 0.0f;
+};
+
+// Row-Panel Hybrid Matrix: dense 16x16 blocks as index tiles (BELL-like) plus
+// the sparse residue as COO relative to the row panel.
+class RPHM {
+public:
+    RPHM() = default;
+    // device < 0: build the host arrays only (no GPU touched).
+    RPHM(const sparseMatrix::CSR<float>& matrix, const BSMR& bsmr, int device = 0);
+    ~RPHM();
+    RPHM(const RPHM&) = delete;
+    RPHM& operator=(const RPHM&) = delete;
+    RPHM(RPHM&& o) noexcept;
+    RPHM& operator=(RPHM&& o) noexcept;
+
+    UIN numRowPanels() const { return numRowPanels_; }
+    UIN maxNumDenseColBlocksInRowPanel() const { return maxNumDenseColBlocksInRowPanel_; }
+    UIN maxNumSparseColBlocksInRowPanel() const { return maxNumSparseColBlocksInRowPanel_; }
+    UIN numDenseThreadBlocks() const { return numDenseThreadBlocks_; }
+    UIN numSparseThreadBlocks() const { return numSparseThreadBlocks_; }
+    const std::vector<UIN>& reorderedRows() const { return reorderedRows_; }
+    const std::vector<UIN>& denseCols() const { return denseCols_; }
+    const std::vector<UIN>& blockValues() const { return blockValues_; }
+    const std::vector<UIN>& blockOffsets() const { return blockOffsets_; }
+    const std::vector<UIN>& sparseValueOffsets() const { return sparseValueOffsets_; }
+    const std::vector<UIN>& sparseValues() const { return sparseValues_; }
+    const std::vector<UIN>& sparseRelativeRows() const { return sparseRelativeRows_; }
+    const std::vector<UIN>& sparseColIndices() const { return sparseColIndices_; }
+    const std::vector<UIN>& denseRowPanelIds() const { return denseRowPanelIds_; }
+    const std::vector<UIN>& denseColBlockIters() const { return denseColBlockIters_; }
+    const std::vector<UIN>& sparseRowPanelIds() const { return sparseRowPanelIds_; }
+    const std::vector<UIN>& sparseColBlockIters() const { return sparseColBlockIters_; }
+
+    float time() const { return reorderingTime_; }
+
+    // Device-resident form (nullptr when built with device < 0 or when plan
+    // creation failed; planStatus() then holds the bsmr_hip.h status code).
+    bsmr_plan* plan() const { return plan_; }
+    int planStatus() const { return planStatus_; }
+
+    UIN calculateRowPanelIdByBlockValuesIndex(UIN blockValueIndex) const;
+    std::pair<UIN, UIN> calculateLocalRowColByBlockValueIndex(UIN blockValueIndex) const;
+    std::pair<UIN, UIN> calculateRowColByBlockValueIndex(UIN blockValueIndex) const;
+    UIN calculateColBlockIdByBlockValueIndex(UIN blockValueIndex) const;
+
+    UIN getNumDenseBlocks() const { return blockOffsets_.empty() ? 0 : blockOffsets_.back(); }
+    UIN getNumSparseBlocks() const;
+    float calculateDenseBlockAverageDensity() const;
+    std::pair<float, float> calculateMaxMinDensity() const;
+    std::pair<float, UIN> calculateDensityMode() const;
+
+private:
+    void release();
+
+    UIN numRowPanels_ = 0;
+    UIN maxNumDenseColBlocksInRowPanel_ = 0;
+    UIN maxNumSparseColBlocksInRowPanel_ = 0;
+    UIN numDenseThreadBlocks_ = 0;
+    UIN numSparseThreadBlocks_ = 0;
+    UIN numCols_ = 0;
+
+    std::vector<UIN> reorderedRows_;
+    std::vector<UIN> denseCols_;
+    std::vector<UIN> blockOffsets_;
+    std::vector<UIN> blockValues_;
+    std::vector<UIN> sparseValueOffsets_;
+    std::vector<UIN> sparseValues_;
+    std::vector<UIN> sparseRelativeRows_;
+    std::vector<UIN> sparseColIndices_;
+    std::vector<UIN> denseRowPanelIds_;
+    std::vector<UIN> denseColBlockIters_;
+    std::vector<UIN> sparseRowPanelIds_;
+    std::vector<UIN> sparseColBlockIters_;
+
+    float reorderingTime_ = 0.0f;
+    bsmr_plan* plan_ = nullptr;
+    int planStatus_ = 0;
+};
+
+// Identity order over the non-empty rows (reference src/rowReordering.cu:15-46).
+void noReorderRow(const sparseMatrix::CSR<float>& matrix, std::vector<UIN>& reorderedRows, float& time);
+
+// Histogram bin width of the row clustering (reference src/rowReordering.cu:1009-1025):
+// max(16, ceil(rows^2*4 / (freeDeviceBytes/2)), ceil(cols*4 / 24576)).  The free
+// memory figure comes from the device when one is present, else 288 GB is assumed.
+UIN calculateBlockSize(const sparseMatrix::CSR<float>& matrix);
+UIN calculateBlockSize(const sparseMatrix::CSR<float>& matrix, size_t freeDeviceBytes);
+
+// BSA row clustering (reference bsa_rowReordering_gpu, src/rowReordering.cu:1027-1095,
+// whose mutex pipeline is equivalent to finishing cluster c before c+1 starts).
+// Host implementation over sparse histograms with an inverted bin index.
+std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, const float alpha,
+                                        const UIN block_size, int& num_clusters,
+                                        float& reordering_time);
+
+// Source-compatible name of the reference entry point; runs the host clustering.
+inline std::vector<UIN> bsa_rowReordering_gpu(const sparseMatrix::CSR<float>& matrix,
+                                              const float alpha, const UIN block_size,
+                                              int& num_clusters, float& reordering_time) {
+    return bsa_rowReordering_host(matrix, alpha, block_size, num_clusters, reordering_time);
+}
+
+// Per-panel column reordering and dense/sparse split (reference
+// src/colReordering.cu:274-404).
+void colReordering_cpu(const sparseMatrix::CSR<float>& matrix, const UIN numRowPanels,
+                       const std::vector<UIN>& reorderedRows, const float blockDensityThreshold,
+                       std::vector<UIN>& denseCols, std::vector<UIN>& denseColOffsets,
+                       std::vector<UIN>& sparseCols, std::vector<UIN>& sparseColOffsets,
+                       std::vector<UIN>& sparseDataOffsets, float& time);
+
+// (#dense column slots, #sparse column slots) of one panel whose per-column
+// counts are sorted descending and padded to a multiple of 16 (reference
+// src/colReordering.cu:244-271).
+std::pair<UIN, UIN> analysisDescendingOrderColSegment(
+    const float blockDensityThreshold, const std::vector<UIN>& numOfNonZeroInEachColSegment);
+
+// Structural validation (reference src/BSMR.cpp:444-824, 932-953).
+bool check_rphm(const sparseMatrix::CSR<float>& matrix, const BSMR& bsmr, const RPHM& rphm,
+                const float denseColSegmentThreshold);
+
+std::pair<UIN, float> calculateNumDenseBlocksAndAverageDensityInOriginalMatrix(
+    const float densityThreshold, const sparseMatrix::CSR<float>& matrix);
+
+void evaluationReordering(const sparseMatrix::CSR<float>& matrix, const BSMR& bsmr, Logger& logger);

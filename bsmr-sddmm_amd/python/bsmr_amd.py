@@ -1,0 +1,380 @@
+"""ctypes bindings of the MI355X BSMR-SDDMM engine.
+
+Binds the two C ABIs declared in /include:
+  * bsmr_hip.h  (lib/libbsmr_hip.so)  -- device plan + HIP kernels
+  * bsmr_host.h (lib/libbsmr_host.so) -- host BSMR pipeline (C++/OpenMP)
+
+This module is plumbing for tests and bench.py; it contains no arithmetic.  If
+the libraries are missing it raises: there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent.parent
+LIB_DIR = PKG_DIR / "lib"
+
+OK = 0
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED_K, ERR_OOM, ERR_BAD_PLAN = 1, 2, 3, 4, 5, 6
+COMPUTE_F16, COMPUTE_BF16, COMPUTE_F32 = 0, 1, 2
+ROWS_CLUSTER, ROWS_IDENTITY = 0, 1
+
+ARRAY_IDS = {
+    "reorderedRows": 0, "denseCols": 1, "denseColOffsets": 2, "sparseCols": 3,
+    "sparseColOffsets": 4, "sparseValueOffsets": 5, "blockOffsets": 6, "blockValues": 7,
+    "sparseValues": 8, "sparseRelativeRows": 9, "sparseColIndices": 10,
+    "denseRowPanelIds": 11, "denseColBlockIters": 12, "sparseRowPanelIds": 13,
+    "sparseColBlockIters": 14,
+}
+
+u32p = C.POINTER(C.c_uint32)
+f32p = C.POINTER(C.c_float)
+
+
+class RphmDesc(C.Structure):
+    _fields_ = [("M", C.c_uint32), ("N", C.c_uint32), ("nnz", C.c_uint32),
+                ("num_row_panels", C.c_uint32), ("num_nonzero_rows", C.c_uint32),
+                ("reordered_rows", u32p), ("dense_cols", u32p), ("block_offsets", u32p),
+                ("block_values", u32p), ("sparse_value_offsets", u32p), ("sparse_values", u32p),
+                ("sparse_relative_rows", u32p), ("sparse_col_indices", u32p)]
+
+
+class PlanStats(C.Structure):
+    _fields_ = [("num_row_panels", C.c_uint32), ("num_dense_blocks", C.c_uint64),
+                ("num_dense_entries", C.c_uint64), ("num_sparse_entries", C.c_uint64),
+                ("dense_work_items", C.c_uint64), ("sparse_work_items", C.c_uint64),
+                ("device_index_bytes", C.c_uint64)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("convert_ms", C.c_float), ("dense_ms", C.c_float),
+                ("sparse_ms", C.c_float)]
+
+
+# every symbol the two headers declare: name -> (restype, argtypes)
+HIP_SYMBOLS = {
+    "bsmr_strerror": (C.c_char_p, [C.c_int]),
+    "bsmr_last_hip_error": (C.c_char_p, []),
+    "bsmr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "bsmr_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "bsmr_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "bsmr_dev_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "bsmr_dev_free": (C.c_int, [C.c_void_p]),
+    "bsmr_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bsmr_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bsmr_dev_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
+    "bsmr_device_synchronize": (C.c_int, [C.c_int]),
+    "bsmr_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RphmDesc)]),
+    "bsmr_plan_destroy": (C.c_int, [C.c_void_p]),
+    "bsmr_plan_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
+    "bsmr_plan_reserve": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "bsmr_sddmm": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                             C.c_void_p]),
+    "bsmr_sddmm_timed": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(Timing)]),
+    "bsmr_convert_operands": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_void_p]),
+    "bsmr_sddmm_lowp": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "bsmr_sddmm_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_int, C.POINTER(C.c_float)]),
+}
+
+HOST_SYMBOLS = {
+    "bsmr_csr_from_file": (C.c_void_p, [C.c_char_p]),
+    "bsmr_csr_from_arrays": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bsmr_csr_free": (None, [C.c_void_p]),
+    "bsmr_csr_rows": (C.c_uint32, [C.c_void_p]),
+    "bsmr_csr_cols": (C.c_uint32, [C.c_void_p]),
+    "bsmr_csr_nnz": (C.c_uint32, [C.c_void_p]),
+    "bsmr_csr_row_offsets": (u32p, [C.c_void_p]),
+    "bsmr_csr_col_indices": (u32p, [C.c_void_p]),
+    "bsmr_csr_values": (f32p, [C.c_void_p]),
+    "bsmr_csr_check": (C.c_int, [C.c_void_p]),
+    "bsmr_csr_write_mtx": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "bsmr_make_data": (None, [C.c_void_p, C.c_size_t, C.c_uint32]),
+    "bsmr_calculate_block_size": (C.c_uint32, [C.c_void_p, C.c_size_t]),
+    "bsmr_pipeline_create": (C.c_void_p, [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_uint32, C.c_int]),
+    "bsmr_pipeline_free": (None, [C.c_void_p]),
+    "bsmr_pipeline_resplit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int]),
+    "bsmr_pipeline_array": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(u32p), C.POINTER(C.c_size_t)]),
+    "bsmr_pipeline_num_row_panels": (C.c_int, [C.c_void_p]),
+    "bsmr_pipeline_num_clusters": (C.c_int, [C.c_void_p]),
+    "bsmr_pipeline_row_reordering_ms": (C.c_float, [C.c_void_p]),
+    "bsmr_pipeline_col_reordering_ms": (C.c_float, [C.c_void_p]),
+    "bsmr_pipeline_rphm_ms": (C.c_float, [C.c_void_p]),
+    "bsmr_pipeline_check": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float]),
+    "bsmr_pipeline_plan": (C.c_void_p, [C.c_void_p]),
+    "bsmr_pipeline_plan_status": (C.c_int, [C.c_void_p]),
+    "bsmr_host_sddmm_cpu": (None, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsmr_host_check_data": (C.c_size_t, [C.c_size_t, C.c_void_p, C.c_void_p]),
+    "bsmr_host_sddmm": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]),
+}
+
+
+def _load(name: str, symbols: dict):
+    path = LIB_DIR / name
+    if not path.exists():
+        raise RuntimeError(
+            f"{path} is missing: build it with `make -C {PKG_DIR}` (or __graft_entry__.build()). "
+            "The engine has no CPU fallback.")
+    lib = C.CDLL(str(path), mode=C.RTLD_GLOBAL)
+    for sym, (res, args) in symbols.items():
+        fn = getattr(lib, sym)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_hip = None
+_host = None
+
+
+def hip():
+    global _hip
+    if _hip is None:
+        _hip = _load("libbsmr_hip.so", HIP_SYMBOLS)
+    return _hip
+
+
+def host():
+    global _host
+    if _host is None:
+        hip()
+        _host = _load("libbsmr_host.so", HOST_SYMBOLS)
+    return _host
+
+
+class BsmrError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        msg = hip().bsmr_strerror(status).decode()
+        detail = hip().bsmr_last_hip_error().decode()
+        super().__init__(f"{where}: {msg}" + (f" ({detail})" if detail else ""))
+
+
+def _check(status: int, where: str):
+    if status != OK:
+        raise BsmrError(status, where)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(hip().bsmr_device_count(C.byref(n)), "bsmr_device_count")
+    return n.value
+
+
+def make_data(count: int, seed: int) -> np.ndarray:
+    """U[0,2) operands, bit-identical to Matrix<float>::makeDataSeeded(seed)."""
+    out = np.empty(count, dtype=np.float32)
+    host().bsmr_make_data(_ptr(out), count, seed)
+    return out
+
+
+class CSR:
+    """sparseMatrix::CSR<float> (pattern owner)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise ValueError("CSR construction failed (the loader returned false)")
+        self._h = C.c_void_p(handle)
+
+    @classmethod
+    def from_file(cls, path) -> "CSR":
+        return cls(host().bsmr_csr_from_file(str(path).encode()))
+
+    @classmethod
+    def from_arrays(cls, rows, cols, row_offsets, col_indices) -> "CSR":
+        ro = np.ascontiguousarray(row_offsets, dtype=np.uint32)
+        ci = np.ascontiguousarray(col_indices, dtype=np.uint32)
+        assert ro.size == rows + 1
+        return cls(host().bsmr_csr_from_arrays(rows, cols, int(ci.size), _ptr(ro), _ptr(ci)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _host is not None:
+            _host.bsmr_csr_free(self._h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    rows = property(lambda s: host().bsmr_csr_rows(s._h))
+    cols = property(lambda s: host().bsmr_csr_cols(s._h))
+    nnz = property(lambda s: host().bsmr_csr_nnz(s._h))
+
+    @property
+    def row_offsets(self) -> np.ndarray:
+        return np.ctypeslib.as_array(host().bsmr_csr_row_offsets(self._h), (self.rows + 1,)).copy()
+
+    @property
+    def col_indices(self) -> np.ndarray:
+        if self.nnz == 0:
+            return np.zeros(0, dtype=np.uint32)
+        return np.ctypeslib.as_array(host().bsmr_csr_col_indices(self._h), (self.nnz,)).copy()
+
+    @property
+    def values(self) -> np.ndarray:
+        if self.nnz == 0:
+            return np.zeros(0, dtype=np.float32)
+        return np.ctypeslib.as_array(host().bsmr_csr_values(self._h), (self.nnz,)).copy()
+
+    def check(self) -> bool:
+        return bool(host().bsmr_csr_check(self._h))
+
+    def write_mtx(self, path) -> bool:
+        return bool(host().bsmr_csr_write_mtx(self._h, str(path).encode()))
+
+    def calculate_block_size(self, free_device_bytes: int) -> int:
+        return host().bsmr_calculate_block_size(self._h, free_device_bytes)
+
+
+class Pipeline:
+    """BSMR(alpha, delta, S) + RPHM(S, bsmr).  device=-1 keeps everything on the host."""
+
+    def __init__(self, csr: CSR, alpha=0.3, delta=0.3, row_mode=ROWS_CLUSTER, block_size=0, device=-1):
+        self.csr = csr
+        self.delta = delta
+        h = host().bsmr_pipeline_create(csr.handle, alpha, delta, row_mode, block_size, device)
+        if not h:
+            raise RuntimeError("bsmr_pipeline_create failed")
+        self._h = C.c_void_p(h)
+        if device >= 0:
+            _check(host().bsmr_pipeline_plan_status(self._h), "bsmr_plan_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _host is not None:
+            _host.bsmr_pipeline_free(self._h)
+            self._h = None
+
+    def resplit(self, delta: float, device=-1):
+        _check(host().bsmr_pipeline_resplit(self._h, self.csr.handle, delta, device), "resplit")
+        self.delta = delta
+
+    def array(self, name: str) -> np.ndarray:
+        data = u32p()
+        n = C.c_size_t(0)
+        _check(host().bsmr_pipeline_array(self._h, ARRAY_IDS[name], C.byref(data), C.byref(n)), name)
+        if n.value == 0:
+            return np.zeros(0, dtype=np.uint32)
+        return np.ctypeslib.as_array(data, (n.value,)).copy()
+
+    def arrays(self) -> dict:
+        return {k: self.array(k) for k in ARRAY_IDS}
+
+    num_row_panels = property(lambda s: host().bsmr_pipeline_num_row_panels(s._h))
+    num_clusters = property(lambda s: host().bsmr_pipeline_num_clusters(s._h))
+    row_reordering_ms = property(lambda s: host().bsmr_pipeline_row_reordering_ms(s._h))
+    col_reordering_ms = property(lambda s: host().bsmr_pipeline_col_reordering_ms(s._h))
+    rphm_ms = property(lambda s: host().bsmr_pipeline_rphm_ms(s._h))
+
+    def check(self) -> bool:
+        return bool(host().bsmr_pipeline_check(self._h, self.csr.handle, self.delta))
+
+    @property
+    def plan(self):
+        p = host().bsmr_pipeline_plan(self._h)
+        if not p:
+            raise RuntimeError("this pipeline has no device plan (built with device=-1?)")
+        return C.c_void_p(p)
+
+    def plan_stats(self) -> dict:
+        s = PlanStats()
+        _check(hip().bsmr_plan_get_stats(self.plan, C.byref(s)), "bsmr_plan_get_stats")
+        return {k: getattr(s, k) for k, _ in PlanStats._fields_}
+
+
+def sddmm_cpu(csr: CSR, K: int, A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """The engine's own OpenMP sddmm_cpu (host.cpp)."""
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    B = np.ascontiguousarray(B, dtype=np.float32)
+    P = np.empty(csr.nnz, dtype=np.float32)
+    host().bsmr_host_sddmm_cpu(csr.handle, K, _ptr(A), _ptr(B), _ptr(P))
+    return P
+
+
+def check_data(x: np.ndarray, y: np.ndarray) -> int:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    assert x.size == y.size
+    return int(host().bsmr_host_check_data(x.size, _ptr(x), _ptr(y)))
+
+
+def sddmm_operator(csr: CSR, K: int, A, B, alpha=0.3, delta=0.3, mode=COMPUTE_F16, iters=1):
+    """sddmm(options, A, B, P, logger) on host operands -> (P, log text)."""
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    B = np.ascontiguousarray(B, dtype=np.float32)
+    P = np.empty(csr.nnz, dtype=np.float32)
+    log = C.create_string_buffer(8192)
+    _check(host().bsmr_host_sddmm(csr.handle, K, alpha, delta, mode, iters, _ptr(A), _ptr(B), _ptr(P),
+                                  log, len(log)), "bsmr_host_sddmm")
+    return P, log.value.decode()
+
+
+# --- device entry points (pointers are integers, e.g. torch.Tensor.data_ptr()) ---
+def sddmm(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, mode=COMPUTE_F16, stream: int = 0):
+    _check(hip().bsmr_sddmm(plan, K, A_ptr, B_ptr, P_ptr, mode, stream), "bsmr_sddmm")
+
+
+def sddmm_timed(plan, K, A_ptr, B_ptr, P_ptr, mode=COMPUTE_F16, stream=0, warmup=2, iters=20) -> dict:
+    t = Timing()
+    _check(hip().bsmr_sddmm_timed(plan, K, A_ptr, B_ptr, P_ptr, mode, stream, warmup, iters, C.byref(t)),
+           "bsmr_sddmm_timed")
+    return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+
+def convert_operands(plan, K, A_ptr, B_ptr, A16_ptr, B16_ptr, mode=COMPUTE_F16, stream=0):
+    _check(hip().bsmr_convert_operands(plan, K, A_ptr, B_ptr, A16_ptr, B16_ptr, mode, stream),
+           "bsmr_convert_operands")
+
+
+def sddmm_lowp(plan, K, A16_ptr, B16_ptr, A_ptr, B_ptr, P_ptr, mode=COMPUTE_F16, stream=0):
+    _check(hip().bsmr_sddmm_lowp(plan, K, A16_ptr, B16_ptr, A_ptr, B_ptr, P_ptr, mode, stream),
+           "bsmr_sddmm_lowp")
+
+
+def sddmm_host(plan, K, A: np.ndarray, B: np.ndarray, nnz: int, mode=COMPUTE_F16, iters=1):
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    B = np.ascontiguousarray(B, dtype=np.float32)
+    P = np.empty(nnz, dtype=np.float32)
+    ms = C.c_float(0)
+    _check(hip().bsmr_sddmm_host(plan, K, _ptr(A), _ptr(B), _ptr(P), mode, iters, C.byref(ms)),
+           "bsmr_sddmm_host")
+    return P, ms.value
+
+
+def plan_from_arrays(M, N, nnz, arrays: dict, device=0):
+    """bsmr_plan_create straight from RPHM-layout numpy arrays (what a reference
+    maintainer would pass from RPHM's host vectors).  Returns the plan handle."""
+    keep = {k: np.ascontiguousarray(arrays[k], dtype=np.uint32) for k in
+            ("reorderedRows", "denseCols", "blockOffsets", "blockValues", "sparseValueOffsets",
+             "sparseValues", "sparseRelativeRows", "sparseColIndices")}
+    d = RphmDesc()
+    d.M, d.N, d.nnz = M, N, nnz
+    d.num_nonzero_rows = keep["reorderedRows"].size
+    d.num_row_panels = keep["blockOffsets"].size - 1
+    cast = lambda a: a.ctypes.data_as(u32p)
+    d.reordered_rows = cast(keep["reorderedRows"])
+    d.dense_cols = cast(keep["denseCols"])
+    d.block_offsets = cast(keep["blockOffsets"])
+    d.block_values = cast(keep["blockValues"])
+    d.sparse_value_offsets = cast(keep["sparseValueOffsets"])
+    d.sparse_values = cast(keep["sparseValues"])
+    d.sparse_relative_rows = cast(keep["sparseRelativeRows"])
+    d.sparse_col_indices = cast(keep["sparseColIndices"])
+    out = C.c_void_p()
+    st = hip().bsmr_plan_create(C.byref(out), device, C.byref(d))
+    return st, out
+
+
+def plan_destroy(plan):
+    hip().bsmr_plan_destroy(plan)

@@ -1,0 +1,156 @@
+"""Deterministic synthetic sparsity patterns for the BASELINE.json configurations.
+
+None of the configuration matrices (nips, cop20k_A, reddit, DLMC) exists in the
+container or on the GPU box (no network; the reference's dataset/nips.mtx is a
+missing large blob), so every configuration has a seeded stand-in of the same
+shape and nnz.  Each generator returns
+(rows, cols, rowOffsets uint32[rows+1], colIndices uint32[nnz]) with ascending
+column ids inside a row (what a sorted .mtx file would load as).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _rows_to_csr(rows: int, cols: int, per_row_cols: list):
+    ro = np.zeros(rows + 1, dtype=np.uint32)
+    for r, c in enumerate(per_row_cols):
+        ro[r + 1] = ro[r] + len(c)
+    ci = np.concatenate(per_row_cols).astype(np.uint32) if rows else np.zeros(0, np.uint32)
+    return rows, cols, ro, ci
+
+
+def _fit_counts(raw: np.ndarray, total: int, cap: int) -> np.ndarray:
+    """Scale non-negative weights to integers in [0, cap] that sum to `total`."""
+    w = np.maximum(raw.astype(np.float64), 0)
+    c = np.minimum(np.floor(w * (total / w.sum())).astype(np.int64), cap)
+    i = 0
+    order = np.argsort(-w, kind="stable")
+    while c.sum() < total:  # hand the remainder to the heaviest rows
+        j = order[i % len(order)]
+        if c[j] < cap:
+            c[j] += 1
+        i += 1
+    return c
+
+
+def nips_like(rows=1500, cols=12419, nnz=746316, seed=1):
+    """Bag-of-words shape (UCI NIPS dimensions): lognormal row lengths (mean ~498),
+    Zipf(1.0) column popularity sampled without replacement inside a row."""
+    rng = np.random.default_rng(seed)
+    counts = _fit_counts(rng.lognormal(mean=0.0, sigma=0.6, size=rows), nnz, cols)
+    logp = -np.log(np.arange(1, cols + 1, dtype=np.float64))
+    perm = rng.permutation(cols)  # popular words are not the low column ids
+    per_row = []
+    for r in range(rows):
+        k = int(counts[r])
+        if k == 0:
+            per_row.append(np.zeros(0, dtype=np.int64))
+            continue
+        keys = logp + rng.gumbel(size=cols)  # Gumbel top-k = weighted sampling w/o replacement
+        top = np.argpartition(-keys, k - 1)[:k]
+        per_row.append(np.sort(perm[top]))
+    return _rows_to_csr(rows, cols, per_row)
+
+
+def banded_mesh_like(n=121192, nnz=1362087, seed=2, empty_frac=0.18):
+    """cop20k_A stand-in: strictly lower-triangular 2-D-mesh-like band (offsets
+    within ~sqrt(n)) plus 5 % uniformly random long-range entries, ~18 % empty rows."""
+    rng = np.random.default_rng(seed)
+    w = rng.gamma(shape=4.0, scale=1.0, size=n)
+    w[rng.random(n) < empty_frac] = 0
+    w[0] = 0  # row 0 has no strictly-lower entries
+    cap = np.minimum(np.arange(n), 64)
+    counts = np.minimum(_fit_counts(w, nnz, 64), cap)
+    deficit = nnz - int(counts.sum())
+    r = n - 1
+    while deficit > 0:  # refill from the bottom rows, which have the most room
+        room = int(cap[r] - counts[r])
+        if room > 0 and counts[r] > 0:
+            take = min(room, deficit)
+            counts[r] += take
+            deficit -= take
+        r -= 1
+        if r < 1:
+            r = n - 1
+    band = int(np.sqrt(n))
+    per_row = []
+    for i in range(n):
+        k = int(counts[i])
+        if k == 0:
+            per_row.append(np.zeros(0, dtype=np.int64))
+            continue
+        lo = max(0, i - band)
+        chosen = set()
+        while len(chosen) < k:
+            need = k - len(chosen)
+            near = rng.integers(lo, i, size=need)
+            far = rng.integers(0, i, size=need)
+            pick = np.where(rng.random(need) < 0.05, far, near)
+            chosen.update(int(x) for x in pick)
+            if i <= k:  # tiny rows: take everything available
+                chosen = set(range(i))
+                break
+        per_row.append(np.sort(np.fromiter(list(chosen)[:k] if len(chosen) > k else chosen,
+                                           dtype=np.int64)))
+    rows, cols, ro, ci = _rows_to_csr(n, n, per_row)
+    return rows, cols, ro, ci
+
+
+def bernoulli(rows=4096, cols=4096, density=0.1, seed=4):
+    """DLMC-style unstructured mask: i.i.d. Bernoulli(density)."""
+    rng = np.random.default_rng(seed)
+    per_row = [np.nonzero(rng.random(cols) < density)[0] for _ in range(rows)]
+    return _rows_to_csr(rows, cols, per_row)
+
+
+def community_graph(n=4096, avg_degree=64, communities=8, inside=0.8, seed=3):
+    """reddit-like shape at a configurable size: power-law out-degrees, `inside` of
+    a row's edges fall in its own community (contiguous id range)."""
+    rng = np.random.default_rng(seed)
+    deg = _fit_counts(rng.pareto(1.5, size=n) + 0.2, n * avg_degree, n // 2)
+    size = n // communities
+    per_row = []
+    for i in range(n):
+        k = int(deg[i])
+        if k == 0:
+            per_row.append(np.zeros(0, dtype=np.int64))
+            continue
+        c0 = (i // size) * size
+        c1 = min(c0 + size, n)
+        chosen = set()
+        while len(chosen) < k:
+            need = k - len(chosen)
+            a = rng.integers(c0, c1, size=need)
+            b = rng.integers(0, n, size=need)
+            chosen.update(int(x) for x in np.where(rng.random(need) < inside, a, b))
+        per_row.append(np.sort(np.fromiter(list(chosen)[:k], dtype=np.int64)))
+    return _rows_to_csr(n, n, per_row)
+
+
+def random_pattern(rows, cols, nnz, seed, empty_rows=0):
+    """Small uniformly random pattern for unit tests (optionally with empty rows)."""
+    rng = np.random.default_rng(seed)
+    live = np.ones(rows, dtype=bool)
+    if empty_rows:
+        live[rng.choice(rows, size=empty_rows, replace=False)] = False
+    cells = np.flatnonzero(np.repeat(live, cols))
+    pick = np.sort(rng.choice(cells, size=min(nnz, cells.size), replace=False))
+    r, c = pick // cols, pick % cols
+    ro = np.zeros(rows + 1, dtype=np.uint32)
+    np.add.at(ro, r + 1, 1)
+    return rows, cols, np.cumsum(ro).astype(np.uint32), c.astype(np.uint32)
+
+
+def write_mtx(path, rows, cols, ro, ci, shuffle_seed=None, values=None):
+    """MatrixMarket coordinate file of the pattern (optionally in shuffled line order)."""
+    r = np.repeat(np.arange(rows), np.diff(ro.astype(np.int64)))
+    order = np.arange(ci.size)
+    if shuffle_seed is not None:
+        order = np.random.default_rng(shuffle_seed).permutation(ci.size)
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{rows} {cols} {ci.size}\n")
+        for i in order:
+            v = 1 if values is None else values[i]
+            f.write(f"{r[i] + 1} {ci[i] + 1} {v}\n")

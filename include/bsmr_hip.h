@@ -1,0 +1,153 @@
+/*
+ * bsmr_hip.h -- C ABI of libbsmr_hip.so, the MI355X (gfx950) device side of the
+ * BSMR-SDDMM engine.
+ *
+ * This is the drop-in boundary for the reference's device layer.  What it
+ * replaces in CX9898/BSMR-SDDMM (paths relative to the reference checkout):
+ *
+ *   bsmr_plan_create     <- the twelve h2d() uploads at the end of RPHM::RPHM
+ *                           (src/BSMR.cpp:252-264); takes the same host arrays
+ *                           the reference's RPHM holds (include/BSMR.hpp:133-158)
+ *   bsmr_plan_destroy    <- ~RPHM / dev::vector destructors (include/devVector.cuh:54-126)
+ *   bsmr_sddmm           <- sddmm_gpu(M,N,K, A_dev, B_dev, rphm, P_dev, logger) and
+ *                           sddmm_gpu_k32(...) (include/sddmmKernel.cuh:25-39,
+ *                           src/sddmmKernel.cu:2540-2762): device pointers in,
+ *                           P written in S's CSR order
+ *   bsmr_sddmm_timed     <- the 10x event-timed loop inside those launchers
+ *                           (src/sddmmKernel.cu:2561-2565,2650-2653)
+ *   bsmr_sddmm_host      <- sddmm_gpu(Matrix A, Matrix B, rphm, CSR P, logger)
+ *                           (src/sddmmKernel.cu:2518-2538): host operands in, host P out
+ *   bsmr_convert_operands / bsmr_sddmm_lowp
+ *                        <- no reference counterpart (the reference converts to
+ *                           TF32 in registers); lets a caller that already holds
+ *                           fp16/bf16 operands skip the per-call conversion
+ *   bsmr_mem_info        <- cudaMemGetInfo in calculateBlockSize (src/rowReordering.cu:1010-1013)
+ *   bsmr_dev_alloc / bsmr_dev_free / bsmr_memcpy_h2d / bsmr_memcpy_d2h / bsmr_dev_memset
+ *                        <- dev::vector<T> ctor/dtor and h2d()/d2h() (include/devVector.cuh:54-126,
+ *                           170-229): raw device buffers owned by the caller
+ *
+ * Only PODs and raw pointers cross.  Every function returns a status code and
+ * never throws or aborts.  A plan is bound to one device; calls on one plan
+ * must come from one thread at a time.  `stream` is a hipStream_t passed as
+ * void* (NULL = the default stream); all device work of a call is ordered on it.
+ */
+#ifndef BSMR_HIP_H
+#define BSMR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSMR_OK                 0
+#define BSMR_ERR_INVALID_ARG    1  /* NULL pointer, inconsistent sizes            */
+#define BSMR_ERR_NO_DEVICE      2  /* no usable gfx950 device / bad device index  */
+#define BSMR_ERR_HIP            3  /* a HIP runtime call failed (see last error)  */
+#define BSMR_ERR_UNSUPPORTED_K  4  /* K == 0 or K not a multiple of 32            */
+#define BSMR_ERR_OOM            5  /* host or device allocation failed            */
+#define BSMR_ERR_BAD_PLAN       6  /* index arrays violate the RPHM invariants    */
+
+/* Arithmetic of the dense-block path (the sparse residual path is always fp32). */
+#define BSMR_COMPUTE_F16   0  /* operands rounded RNE to fp16, fp32 accumulate (default;
+                                 same 10-bit mantissa as the reference's TF32)       */
+#define BSMR_COMPUTE_BF16  1  /* operands rounded RNE to bf16, fp32 accumulate         */
+#define BSMR_COMPUTE_F32   2  /* exact fp32 (v_mfma_f32_16x16x4_f32), 1/16 MFMA rate   */
+
+typedef struct bsmr_plan bsmr_plan;
+
+/* Host-side index arrays of one reordered matrix: exactly the members of the
+ * reference's RPHM before upload.  All arrays are read during plan_create and
+ * need not outlive it. */
+typedef struct bsmr_rphm_desc {
+    uint32_t M, N, nnz;
+    uint32_t num_row_panels;          /* ceil(num_nonzero_rows / 16)                          */
+    uint32_t num_nonzero_rows;        /* length of reordered_rows                             */
+    const uint32_t *reordered_rows;   /* [num_nonzero_rows] original row of each panel row    */
+    const uint32_t *dense_cols;       /* [16 * block_offsets[P]] column ids, N = padding      */
+    const uint32_t *block_offsets;    /* [P+1] dense 16x16 blocks before each panel           */
+    const uint32_t *block_values;     /* [256 * block_offsets[P]] CSR index or 0xFFFFFFFF,
+                                         row-major 16x16 per block                            */
+    const uint32_t *sparse_value_offsets; /* [P+1] sparse entries before each panel           */
+    const uint32_t *sparse_values;        /* CSR index of each sparse entry                   */
+    const uint32_t *sparse_relative_rows; /* row inside the panel, 0..15                      */
+    const uint32_t *sparse_col_indices;   /* column id                                        */
+} bsmr_rphm_desc;
+
+typedef struct bsmr_plan_stats {
+    uint32_t num_row_panels;
+    uint64_t num_dense_blocks;
+    uint64_t num_dense_entries;   /* nnz covered by the dense path  */
+    uint64_t num_sparse_entries;  /* nnz covered by the sparse path */
+    uint64_t dense_work_items;    /* waves launched by the dense kernel        */
+    uint64_t sparse_work_items;   /* workgroups launched by the sparse kernel  */
+    uint64_t device_index_bytes;  /* bytes of plan metadata resident in HBM    */
+} bsmr_plan_stats;
+
+/* Kernel timings of the last bsmr_sddmm_timed call, milliseconds per iteration. */
+typedef struct bsmr_timing {
+    float total_ms;    /* convert + dense + sparse, wall on the stream          */
+    float convert_ms;  /* fp32 -> fp16/bf16 operand pass (0 in F32 mode)        */
+    float dense_ms;    /* dense-block MFMA kernel                               */
+    float sparse_ms;   /* residual sparse kernel                                */
+} bsmr_timing;
+
+const char *bsmr_strerror(int status);
+/* Text of the last HIP error seen by this library on the calling thread. */
+const char *bsmr_last_hip_error(void);
+
+int bsmr_device_count(int *count);
+int bsmr_mem_info(int device, size_t *free_bytes, size_t *total_bytes);
+int bsmr_device_name(int device, char *buf, size_t buflen);
+
+/* Caller-owned device buffers on `device` (synchronous copies). */
+int bsmr_dev_alloc(int device, size_t bytes, void **out);
+int bsmr_dev_free(void *ptr);
+int bsmr_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int bsmr_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int bsmr_dev_memset(void *dst_dev, int value, size_t bytes);
+int bsmr_device_synchronize(int device);
+
+int bsmr_plan_create(bsmr_plan **out, int device, const bsmr_rphm_desc *desc);
+int bsmr_plan_destroy(bsmr_plan *plan);
+int bsmr_plan_get_stats(const bsmr_plan *plan, bsmr_plan_stats *out);
+
+/* Grow the plan's operand workspace for inner dimension K now (otherwise it
+ * grows on first use, which allocates and therefore must not happen inside a
+ * stream capture). */
+int bsmr_plan_reserve(bsmr_plan *plan, uint32_t K);
+
+/* One SDDMM: A_dev is M x K row-major fp32, B_dev is K x N column-major fp32
+ * (column j = K contiguous floats at B_dev + j*K), P_dev receives nnz floats in
+ * S's CSR order.  Every element of P_dev is overwritten. */
+int bsmr_sddmm(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev,
+               float *P_dev, int compute_mode, void *stream);
+
+/* warmup + iters repetitions of bsmr_sddmm bracketed by HIP events on `stream`;
+ * per-kernel times are measured in a second pass of `iters` repetitions with
+ * events around each kernel. */
+int bsmr_sddmm_timed(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev,
+                     float *P_dev, int compute_mode, void *stream, int warmup, int iters,
+                     bsmr_timing *out);
+
+/* Convert fp32 operands once (mode F16 or BF16); A16_dev / B16_dev are M*K and
+ * N*K 16-bit elements in the same layouts. */
+int bsmr_convert_operands(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev,
+                          void *A16_dev, void *B16_dev, int compute_mode, void *stream);
+
+/* SDDMM on pre-converted operands.  The dense path reads A16/B16; the sparse
+ * residual path reads A_dev/B_dev (fp32) when given, else widens A16/B16. */
+int bsmr_sddmm_lowp(bsmr_plan *plan, uint32_t K, const void *A16_dev, const void *B16_dev,
+                    const float *A_dev, const float *B_dev, float *P_dev, int compute_mode,
+                    void *stream);
+
+/* Host operands in, host P out (upload, `iters` timed repetitions after one
+ * warm-up, download).  ms_per_iter may be NULL. */
+int bsmr_sddmm_host(bsmr_plan *plan, uint32_t K, const float *A_host, const float *B_host,
+                    float *P_host, int compute_mode, int iters, float *ms_per_iter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSMR_HIP_H */

@@ -1,0 +1,115 @@
+import ctypes as C
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "bsmr-sddmm_amd" / "python"))
+sys.path.insert(0, str(REPO / "oracle"))
+sys.path.insert(0, str(REPO))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    need = [REPO / "bsmr-sddmm_amd" / "lib" / "libbsmr_hip.so",
+            REPO / "bsmr-sddmm_amd" / "lib" / "libbsmr_host.so",
+            REPO / "oracle" / "liboracle.so"]
+    if all(p.exists() for p in need):
+        return
+    import __graft_entry__
+    __graft_entry__.build()
+
+
+@pytest.fixture(scope="session")
+def engine():
+    _ensure_built()
+    import bsmr_amd
+    bsmr_amd.host()
+    return bsmr_amd
+
+
+class Oracle:
+    """ctypes view of oracle/liboracle.so (the checker; never the thing under test)."""
+
+    def __init__(self):
+        self.lib = C.CDLL(str(REPO / "oracle" / "liboracle.so"))
+        L = self.lib
+        vp = C.c_void_p
+        L.oracle_sddmm_cpu.argtypes = [C.c_uint32] * 3 + [vp] * 5
+        L.oracle_sddmm_f64.argtypes = [C.c_uint32] * 2 + [vp] * 5
+        L.oracle_check_one.argtypes = [C.c_float, C.c_float]
+        L.oracle_check_one.restype = C.c_int
+        L.oracle_check_data.argtypes = [C.c_uint64, vp, vp, C.POINTER(C.c_int64)]
+        L.oracle_check_data.restype = C.c_uint64
+        for f in ("oracle_round_tf32", "oracle_round_fp16", "oracle_round_bf16"):
+            getattr(L, f).argtypes = [C.c_float]
+            getattr(L, f).restype = C.c_float
+        L.oracle_round_array.argtypes = [C.c_int, C.c_uint64, vp, vp]
+        L.oracle_sddmm_ref_kernel_model.argtypes = [C.c_uint32] * 2 + [vp] * 6
+        L.oracle_sparse_twin.argtypes = [C.c_uint32] * 3 + [vp] * 5
+        L.oracle_dense_f32_twin.argtypes = [C.c_uint32] * 2 + [vp] * 5
+        L.oracle_dense_lowp_model.argtypes = [C.c_int] + [C.c_uint32] * 2 + [vp] * 5
+        L.oracle_num_threads.restype = C.c_int
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def sddmm_cpu(self, M, N, K, ro, ci, A, B):
+        P = np.empty(ci.size, dtype=np.float32)
+        self.lib.oracle_sddmm_cpu(M, N, K, self._p(ro), self._p(ci), self._p(A), self._p(B), self._p(P))
+        return P
+
+    def sddmm_f64(self, M, K, ro, ci, A, B):
+        P = np.empty(ci.size, dtype=np.float64)
+        self.lib.oracle_sddmm_f64(M, K, self._p(ro), self._p(ci), self._p(A), self._p(B), self._p(P))
+        return P
+
+    def check_data(self, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        first = C.c_int64(-1)
+        n = self.lib.oracle_check_data(x.size, self._p(x), self._p(y), C.byref(first))
+        return int(n), int(first.value)
+
+    def round_array(self, mode, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        out = np.empty_like(a)
+        self.lib.oracle_round_array(mode, a.size, self._p(a), self._p(out))
+        return out
+
+    def ref_kernel_model(self, M, K, ro, ci, is_dense, A, B):
+        P = np.empty(ci.size, dtype=np.float32)
+        d = np.ascontiguousarray(is_dense, dtype=np.uint8)
+        self.lib.oracle_sddmm_ref_kernel_model(M, K, self._p(ro), self._p(ci), self._p(d), self._p(A),
+                                               self._p(B), self._p(P))
+        return P
+
+    def sparse_twin(self, M, K, lpe, ro, ci, A, B):
+        P = np.empty(ci.size, dtype=np.float32)
+        self.lib.oracle_sparse_twin(M, K, lpe, self._p(ro), self._p(ci), self._p(A), self._p(B), self._p(P))
+        return P
+
+    def dense_f32_twin(self, M, K, ro, ci, A, B):
+        P = np.empty(ci.size, dtype=np.float32)
+        self.lib.oracle_dense_f32_twin(M, K, self._p(ro), self._p(ci), self._p(A), self._p(B), self._p(P))
+        return P
+
+    def dense_lowp_model(self, mode, M, K, ro, ci, A, B):
+        P = np.empty(ci.size, dtype=np.float64)
+        self.lib.oracle_dense_lowp_model(mode, M, K, self._p(ro), self._p(ci), self._p(A), self._p(B),
+                                         self._p(P))
+        return P
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    _ensure_built()
+    return Oracle()

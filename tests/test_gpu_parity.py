@@ -1,0 +1,205 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on the same
+seeded inputs.  Bars:
+  * output indexing (which CSR slot every value lands in): bit exact - checked by
+    giving every stored entry a distinct expected value;
+  * sparse residual path and dense F32 mode: bit exact against their CPU twins
+    (defined fmaf chains);
+  * dense F16 / BF16 modes: |got - model| <= (K/32 + 4) * 2^-23 * sum|a*b| against the
+    rounded-operand fp64 model (MFMA-internal summation order is not architectural),
+    and the reference's own acceptance test (checkData, 1e-3 relative) against
+    sddmm_cpu with zero failures.
+"""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+def run_hip(eng, pipe, K, A, B, mode):
+    dev = _dev()
+    tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    tP = torch.full((pipe.csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+    eng.sddmm(pipe.plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), mode,
+              torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    return tP.cpu().numpy()
+
+
+def dense_flags(pipe):
+    """1 for CSR entries computed by the dense-block path, 0 for the sparse residue."""
+    flags = np.zeros(pipe.csr.nnz, dtype=np.uint8)
+    bv = pipe.array("blockValues")
+    flags[bv[bv != 0xFFFFFFFF]] = 1
+    return flags
+
+
+def expected_twin(oracle, pipe, K, ro, ci, A, B, mode, lpe=8):
+    M = pipe.csr.rows
+    flags = dense_flags(pipe).astype(bool)
+    sparse = oracle.sparse_twin(M, K, min(lpe, K // 4), ro, ci, A, B)
+    if mode == 2:
+        dense = oracle.dense_f32_twin(M, K, ro, ci, A, B)
+        return np.where(flags, dense, sparse), flags, None
+    model = oracle.dense_lowp_model(2 if mode == 0 else 3, M, K, ro, ci, A, B)
+    return sparse, flags, model
+
+
+def check_case(eng, oracle, rows, cols, ro, ci, K, alpha, delta, mode, row_mode=0, seedA=5489, seedB=5490):
+    csr = eng.CSR.from_arrays(rows, cols, ro, ci)
+    pipe = eng.Pipeline(csr, alpha=alpha, delta=delta, row_mode=row_mode, device=0)
+    assert pipe.check()
+    A = eng.make_data(rows * K, seedA)
+    B = eng.make_data(cols * K, seedB)
+    got = run_hip(eng, pipe, K, A, B, mode)
+    assert not np.isnan(got).any(), "some stored entry was never written"
+    want_cpu = oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B)
+    bad, first = oracle.check_data(want_cpu, got)
+    assert bad == 0, f"{bad} entries fail the reference tolerance (first {first})"
+    twin, flags, model = expected_twin(oracle, pipe, K, ro, ci, A, B, mode)
+    if mode == 2:
+        assert np.array_equal(got.view(np.uint32), twin.view(np.uint32)), "F32 mode is not bit exact"
+    else:
+        s = ~flags
+        assert np.array_equal(got[s].view(np.uint32), twin[s].view(np.uint32)), "sparse path not bit exact"
+        if flags.any():
+            absdot = oracle.sddmm_f64(rows, K, ro, ci, np.abs(A), np.abs(B))
+            err = np.abs(got[flags].astype(np.float64) - model[flags])
+            bound = (K / 32 + 4) * 2.0 ** -23  # <= ~1 ulp of the running sum per MFMA step
+            assert (err <= bound * absdot[flags] + 1e-30).all(), f"dense lowp error {err.max()}"
+    return pipe
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("K", [32, 64, 128, 256])
+@pytest.mark.parametrize("delta", [0.0, 0.1, 0.3, 1.1])
+def test_small_random(engine, oracle, mode, K, delta):
+    rows, cols, ro, ci = synth.random_pattern(150, 220, 5000, seed=7 + K, empty_rows=9)
+    check_case(engine, oracle, rows, cols, ro, ci, K, 0.3, delta, mode)
+
+
+@pytest.mark.parametrize("K", [96, 160, 512, 1024])
+def test_other_k(engine, oracle, K):
+    # 96/160: run-time K loop of the dense kernel; 512: register-resident K; 1024: sparse
+    # path still stages A in LDS (66 KB needs the no-LDS variant)
+    rows, cols, ro, ci = synth.random_pattern(70, 90, 1500, seed=K)
+    for mode in (0, 2):
+        check_case(engine, oracle, rows, cols, ro, ci, K, 0.3, 0.1, mode)
+
+
+def test_large_k_sparse_without_lds(engine, oracle):
+    rows, cols, ro, ci = synth.random_pattern(40, 50, 400, seed=99)
+    check_case(engine, oracle, rows, cols, ro, ci, 2048, 0.3, 1.1, 0)
+
+
+def test_output_indexing_is_exact(engine, oracle):
+    """A = one-hot rows, B = column id: every entry's exact value identifies (row, col)."""
+    rows, cols, ro, ci = synth.random_pattern(130, 500, 4000, seed=21, empty_rows=4)
+    K = 32
+    A = np.zeros((rows, K), dtype=np.float32)
+    A[:, 0] = np.arange(1, rows + 1) % 64 + 1        # small integers: exact in fp16 and bf16
+    A[:, 1] = 1.0
+    B = np.zeros((cols, K), dtype=np.float32)
+    B[:, 0] = 1.0
+    B[:, 1] = np.arange(cols) % 128
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    r = np.repeat(np.arange(rows), np.diff(ro.astype(np.int64)))
+    want = (A[r, 0] + B[ci, 1]).astype(np.float32)
+    for delta in (0.0, 0.05, 1.1):
+        for mode in (0, 1, 2):
+            pipe = engine.Pipeline(csr, alpha=0.3, delta=delta, device=0)
+            got = run_hip(engine, pipe, K, A.ravel(), B.ravel(), mode)
+            assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 256), (1, 40, 30), (17, 33, 200), (300, 20, 1500), (5, 5, 2)])
+def test_edge_shapes(engine, oracle, shape):
+    rows, cols, nnz = shape
+    rows_, cols_, ro, ci = synth.random_pattern(rows, cols, nnz, seed=sum(shape))
+    for delta in (0.0, 0.3, 1.1):
+        check_case(engine, oracle, rows_, cols_, ro, ci, 64, 0.3, delta, 0)
+
+
+def test_identity_row_order(engine, oracle):
+    rows, cols, ro, ci = synth.random_pattern(200, 200, 4000, seed=5, empty_rows=20)
+    check_case(engine, oracle, rows, cols, ro, ci, 128, 0.3, 0.1, 0, row_mode=1)
+
+
+def test_operator_entry_point(engine, oracle):
+    """sddmm(options, A, B, P, logger) end to end (host operands)."""
+    rows, cols, ro, ci = synth.random_pattern(250, 300, 9000, seed=31)
+    K = 128
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    A = engine.make_data(rows * K, 1)
+    B = engine.make_data(cols * K, 2)
+    P, log = engine.sddmm_operator(csr, K, A, B, alpha=0.3, delta=0.3, iters=3)
+    want = oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B)
+    assert oracle.check_data(want, P)[0] == 0
+    assert "[bsmr_gflops : " in log and "[NNZ : 9000]" in log
+
+
+def test_lowp_operands_entry(engine, oracle):
+    rows, cols, ro, ci = synth.random_pattern(120, 140, 3000, seed=41)
+    K = 128
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    pipe = engine.Pipeline(csr, alpha=0.3, delta=0.1, device=0)
+    A = engine.make_data(rows * K, 3)
+    B = engine.make_data(cols * K, 4)
+    dev = _dev()
+    tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    a16 = torch.empty(rows * K, dtype=torch.float16, device=dev)
+    b16 = torch.empty(cols * K, dtype=torch.float16, device=dev)
+    tP = torch.zeros(csr.nnz, dtype=torch.float32, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    engine.convert_operands(pipe.plan, K, tA.data_ptr(), tB.data_ptr(), a16.data_ptr(), b16.data_ptr(), 0, s)
+    torch.cuda.synchronize()
+    # the conversion is round-to-nearest-even, bit for bit what torch and the oracle produce
+    assert torch.equal(a16, tA.to(torch.float16))
+    assert np.array_equal(a16.float().cpu().numpy(), oracle.round_array(2, A))
+    engine.sddmm_lowp(pipe.plan, K, a16.data_ptr(), b16.data_ptr(), tA.data_ptr(), tB.data_ptr(),
+                      tP.data_ptr(), 0, s)
+    torch.cuda.synchronize()
+    ref = run_hip(engine, pipe, K, A, B, 0)
+    assert np.array_equal(tP.cpu().numpy(), ref)
+
+
+def test_error_codes_on_device(engine):
+    rows, cols, ro, ci = synth.random_pattern(40, 40, 300, seed=2)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    pipe = engine.Pipeline(csr, device=0)
+    hip = engine.hip()
+    assert hip.bsmr_sddmm(pipe.plan, 48, 1, 1, 1, 0, None) == engine.ERR_UNSUPPORTED_K
+    assert hip.bsmr_sddmm(pipe.plan, 0, 1, 1, 1, 0, None) == engine.ERR_UNSUPPORTED_K
+    assert hip.bsmr_sddmm(pipe.plan, 32, None, 1, 1, 0, None) == engine.ERR_INVALID_ARG
+    assert hip.bsmr_sddmm(pipe.plan, 32, 1, 1, 1, 9, None) == engine.ERR_INVALID_ARG
+    # corrupt RPHM arrays are rejected, not launched
+    arr = pipe.arrays()
+    arr["sparseValues"] = arr["sparseValues"].copy()
+    if arr["sparseValues"].size:
+        arr["sparseValues"][0] = csr.nnz + 5
+        st, plan = engine.plan_from_arrays(rows, cols, csr.nnz, arr, device=0)
+        assert st == engine.ERR_BAD_PLAN
+    st, plan = engine.plan_from_arrays(rows, cols, csr.nnz, pipe.arrays(), device=99)
+    assert st == engine.ERR_NO_DEVICE
+
+
+def test_nips_like_full_size(engine, oracle):
+    """BASELINE configs[1]: nips-like 1500 x 12419, nnz 746316, K=128, delta=0 (all dense)."""
+    rows, cols, ro, ci = synth.nips_like()
+    pipe = check_case(engine, oracle, rows, cols, ro, ci, 128, 0.3, 0.0, 0)
+    st = pipe.plan_stats()
+    assert st["num_sparse_entries"] == 0 and st["num_dense_entries"] == 746316
+
+
+def test_nips_like_hybrid_k32(engine, oracle):
+    """BASELINE configs[0] on the GPU: K=32, alpha=0.3, delta=0.3."""
+    rows, cols, ro, ci = synth.nips_like()
+    check_case(engine, oracle, rows, cols, ro, ci, 32, 0.3, 0.3, 0)
