@@ -29,9 +29,9 @@ struct bsmr_plan {
     // device-resident metadata
     uint32_t* panelRows = nullptr;   // [numPanels*16] original row per panel row (padding -> a valid row)
     uint32_t* blockCols = nullptr;   // [numBlocks*16] column per tile column (padding -> column 0)
-    uint64_t* blockMask = nullptr;   // [numBlocks*4]  lane-major occupancy bitmap
-    uint32_t* blockBase = nullptr;   // [numBlocks*4]  offset of each mask word's first destination
-    uint32_t* dstIndex = nullptr;    // [numDenseEntries] CSR index, accumulator order
+    uint32_t* panelRowBase = nullptr; // [numPanels*16] CSR offset that the tile offsets of a panel row add to
+    uint16_t* tiles16 = nullptr;     // [numBlocks*256] lane-major row-relative destinations, 0xFFFF = none
+    uint32_t* tiles32 = nullptr;     // same with 32-bit offsets (only when some row has >= 65535 entries)
     DenseItem* denseItems = nullptr;
     uint32_t* entryCol = nullptr;    // [numSparseEntries]
     uint32_t* entryDst = nullptr;    // [numSparseEntries] CSR index
@@ -96,7 +96,7 @@ int envInt(const char* name, int fallback) {
 }
 
 void freePlanDevice(bsmr_plan* p) {
-    void* ptrs[] = {p->panelRows, p->blockCols, p->blockMask, p->blockBase, p->dstIndex,
+    void* ptrs[] = {p->panelRows, p->blockCols, p->panelRowBase, p->tiles16, p->tiles32,
                     p->denseItems, p->entryCol, p->entryDst, p->entryRow, p->sparseItems,
                     p->A16, p->B16};
     for (void* q : ptrs)
@@ -119,13 +119,20 @@ int launchConvert(const bsmr_plan* p, uint32_t K, const float* A, const float* B
     return BSMR_OK;
 }
 
-template <int KS, int MODE>
+// KS = K/32 (0 = run-time loop), NB = blocks whose loads are batched: KS*NB*4 B-fragment
+// registers per lane, kept at 64 so that several waves per SIMD stay resident.
+template <int KS, int NB, int MODE>
 void launchDense16KS(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
                      hipStream_t s) {
     const uint32_t wgs = gridFor((p->numDenseItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG);
-    hipLaunchKernelGGL((bsmr::denseBlocks16<KS, MODE>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A16, B16,
-                       K, p->panelRows, p->blockCols, p->blockMask, p->blockBase, p->dstIndex,
-                       p->denseItems, p->numDenseItems, P);
+    if (p->tiles16)
+        hipLaunchKernelGGL((bsmr::denseBlocks16<KS, NB, MODE, uint16_t>), dim3(wgs), dim3(bsmr::kThreads), 0,
+                           s, A16, B16, K, p->panelRows, p->panelRowBase, p->blockCols, p->tiles16,
+                           p->denseItems, p->numDenseItems, P);
+    else
+        hipLaunchKernelGGL((bsmr::denseBlocks16<KS, NB, MODE, uint32_t>), dim3(wgs), dim3(bsmr::kThreads), 0,
+                           s, A16, B16, K, p->panelRows, p->panelRowBase, p->blockCols, p->tiles32,
+                           p->denseItems, p->numDenseItems, P);
 }
 
 template <int MODE>
@@ -133,12 +140,12 @@ int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uin
                   hipStream_t s) {
     if (p->numDenseItems == 0) return BSMR_OK;
     switch (K) {
-    case 32: launchDense16KS<1, MODE>(p, K, A16, B16, P, s); break;
-    case 64: launchDense16KS<2, MODE>(p, K, A16, B16, P, s); break;
-    case 128: launchDense16KS<4, MODE>(p, K, A16, B16, P, s); break;
-    case 256: launchDense16KS<8, MODE>(p, K, A16, B16, P, s); break;
-    case 512: launchDense16KS<16, MODE>(p, K, A16, B16, P, s); break;
-    default: launchDense16KS<0, MODE>(p, K, A16, B16, P, s); break;
+    case 32: launchDense16KS<1, 8, MODE>(p, K, A16, B16, P, s); break;
+    case 64: launchDense16KS<2, 8, MODE>(p, K, A16, B16, P, s); break;
+    case 128: launchDense16KS<4, 4, MODE>(p, K, A16, B16, P, s); break;
+    case 256: launchDense16KS<8, 2, MODE>(p, K, A16, B16, P, s); break;
+    case 512: launchDense16KS<16, 1, MODE>(p, K, A16, B16, P, s); break;
+    default: launchDense16KS<0, 1, MODE>(p, K, A16, B16, P, s); break;
     }
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
@@ -148,9 +155,14 @@ int launchDense32(const bsmr_plan* p, uint32_t K, const float* A, const float* B
                   hipStream_t s) {
     if (p->numDenseItems == 0) return BSMR_OK;
     const uint32_t wgs = gridFor((p->numDenseItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG);
-    hipLaunchKernelGGL(bsmr::denseBlocks32, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, p->panelRows,
-                       p->blockCols, p->blockMask, p->blockBase, p->dstIndex, p->denseItems,
-                       p->numDenseItems, P);
+    if (p->tiles16)
+        hipLaunchKernelGGL(bsmr::denseBlocks32<uint16_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           p->panelRows, p->panelRowBase, p->blockCols, p->tiles16, p->denseItems,
+                           p->numDenseItems, P);
+    else
+        hipLaunchKernelGGL(bsmr::denseBlocks32<uint32_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           p->panelRows, p->panelRowBase, p->blockCols, p->tiles32, p->denseItems,
+                           p->numDenseItems, P);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -360,26 +372,48 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
             blockCols[i] = c == d->N ? 0u : c;  // padding column: any readable column, its outputs are masked
         }
 
-        std::vector<uint64_t> blockMask(numBlocks * 4, 0);
-        std::vector<uint32_t> blockBase(numBlocks * 4, 0);
-        std::vector<uint32_t> dstIndex;
-        dstIndex.reserve(d->nnz);
-        for (uint64_t b = 0; b < numBlocks; ++b) {
-            const uint32_t* tile = d->block_values + b * 256;
-            for (uint32_t g = 0; g < 4; ++g) {
-                blockBase[b * 4 + g] = (uint32_t)dstIndex.size();
-                uint64_t word = 0;
-                for (uint32_t c = 0; c < 16; ++c)
-                    for (uint32_t i = 0; i < 4; ++i) {
-                        const uint32_t v = tile[(4 * g + i) * 16 + c];
-                        if (v == 0xFFFFFFFFu) continue;
-                        if (v >= d->nnz) return BSMR_ERR_BAD_PLAN;
-                        word |= 1ull << (4 * c + i);
-                        dstIndex.push_back(v);
-                    }
-                blockMask[b * 4 + g] = word;
+        // Destination tiles.  rowBase of a panel row = smallest CSR index among its
+        // dense entries (= the row's CSR offset when the whole row is dense); tile
+        // element [4*lane + i] = CSR index - rowBase for accumulator register i of
+        // `lane` (tile row 4*(lane>>4)+i, tile column lane&15).
+        std::vector<uint32_t> panelRowBase((size_t)P * 16, 0);
+        uint64_t numDenseEntries = 0;
+        uint32_t maxOffset = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            uint32_t lo[16], hi[16];
+            for (int r = 0; r < 16; ++r) { lo[r] = 0xFFFFFFFFu; hi[r] = 0; }
+            for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b) {
+                const uint32_t* tile = d->block_values + b * 256;
+                for (uint32_t i = 0; i < 256; ++i) {
+                    const uint32_t v = tile[i];
+                    if (v == 0xFFFFFFFFu) continue;
+                    if (v >= d->nnz) return BSMR_ERR_BAD_PLAN;
+                    ++numDenseEntries;
+                    lo[i >> 4] = std::min(lo[i >> 4], v);
+                    hi[i >> 4] = std::max(hi[i >> 4], v);
+                }
+            }
+            for (int r = 0; r < 16; ++r) {
+                if (lo[r] == 0xFFFFFFFFu) continue;
+                panelRowBase[(size_t)p * 16 + r] = lo[r];
+                maxOffset = std::max(maxOffset, hi[r] - lo[r]);
             }
         }
+        const bool wideTiles = maxOffset >= 0xFFFFu || envInt("BSMR_FORCE_TILE32", 0) != 0;
+        std::vector<uint16_t> tiles16(wideTiles ? 0 : numBlocks * 256);
+        std::vector<uint32_t> tiles32(wideTiles ? numBlocks * 256 : 0);
+        for (uint32_t p = 0; p < P; ++p)
+            for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b) {
+                const uint32_t* tile = d->block_values + b * 256;
+                for (uint32_t lane = 0; lane < 64; ++lane)
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        const uint32_t row = 4 * (lane >> 4) + i, col = lane & 15u;
+                        const uint32_t v = tile[row * 16 + col];
+                        const uint32_t off = v == 0xFFFFFFFFu ? 0xFFFFFFFFu : v - panelRowBase[(size_t)p * 16 + row];
+                        if (wideTiles) tiles32[b * 256 + lane * 4 + i] = off;
+                        else tiles16[b * 256 + lane * 4 + i] = (uint16_t)off;
+                    }
+            }
 
         std::vector<uint32_t> entryCol(numSparse), entryDst(numSparse);
         std::vector<uint8_t> entryRow(numSparse);
@@ -391,7 +425,7 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
             entryDst[i] = d->sparse_values[i];
             entryRow[i] = (uint8_t)d->sparse_relative_rows[i];
         }
-        if (dstIndex.size() + numSparse != d->nnz) return BSMR_ERR_BAD_PLAN;
+        if (numDenseEntries + numSparse != d->nnz) return BSMR_ERR_BAD_PLAN;
 
         // ---- work lists ----------------------------------------------------
         // dense: runs of `chunk` blocks of one panel per wave; small enough that
@@ -400,7 +434,8 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         int chunk = envInt("BSMR_DENSE_CHUNK", 0);
         if (chunk <= 0) {
             const uint64_t targetWaves = 256ull * 4 * 6;
-            chunk = (int)std::max<uint64_t>(1, std::min<uint64_t>(16, numBlocks / targetWaves));
+            chunk = (int)std::max<uint64_t>(4, std::min<uint64_t>(16, numBlocks / targetWaves));
+            chunk = (chunk + 3) & ~3;  // whole load batches (NB divides 8) for K <= 128
         }
         std::vector<DenseItem> denseItems;
         for (uint32_t p = 0; p < P; ++p)
@@ -423,7 +458,7 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         p->nnz = d->nnz;
         p->numPanels = P;
         p->numBlocks = numBlocks;
-        p->numDenseEntries = dstIndex.size();
+        p->numDenseEntries = numDenseEntries;
         p->numSparseEntries = numSparse;
         p->numDenseItems = (uint32_t)denseItems.size();
         p->numSparseItems = (uint32_t)sparseItems.size();
@@ -432,9 +467,9 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
 
         st = upload(p->panelRows, panelRows, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->blockCols, blockCols, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->blockMask, blockMask, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->blockBase, blockBase, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->dstIndex, dstIndex, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->panelRowBase, panelRowBase, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->tiles16, tiles16, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->tiles32, tiles32, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->denseItems, denseItems, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->entryCol, entryCol, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->entryDst, entryDst, p->indexBytes);

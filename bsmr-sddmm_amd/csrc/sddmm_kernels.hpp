@@ -13,10 +13,10 @@
 //    K step - no LDS staging, no transposes, no bank conflicts.
 //  * One wave owns one row panel x a run of dense blocks; the panel's A
 //    fragments stay in registers across the run.
-//  * The sparsity mask is a 256-bit bitmap per block in accumulator (lane-major)
-//    order; the destinations are a compact list of CSR indices in the same order,
-//    so a lane finds its outputs with one popcount (the reference stores a 1 KiB
-//    row-major index tile per block).
+//  * The sparsity mask and the destinations are one tile of 256 row-relative
+//    16-bit offsets per block, stored in accumulator (lane-major) order: 8 bytes
+//    per lane, loaded together with the B fragments (the reference stores a 1 KiB
+//    row-major tile of absolute 32-bit indices per block).
 //  * The residual sparse path splits K over LPE lanes per entry (coalesced 16-byte
 //    loads of the B column), takes the panel's A rows from LDS, and reduces with
 //    a butterfly; it is exact fp32 with a defined summation order (bit-level CPU
@@ -92,21 +92,42 @@ convertOperands(const float* __restrict__ A, uint64_t nA8, const float* __restri
 // ---------------------------------------------------------------------------
 // masked write-back of one 16x16 accumulator tile
 //   lane l, register i  <->  tile row 4*(l>>4)+i, tile column l&15
-//   mask word g = l>>4 holds bit 4*(l&15)+i; `base` = offset of the word's first
-//   destination in dstIndex.
+//   The plan stores, per block, 256 destinations in exactly that (lane-major)
+//   order: element [4*l + i] = CSR index of the entry minus the CSR offset of its
+//   row (`rowBase`), or all-ones where S has no entry.  16-bit offsets serve every
+//   matrix whose rows hold < 65535 entries (8 bytes per lane and block); the
+//   32-bit form is the fallback.  The load does not depend on anything computed
+//   by the wave, so it is issued together with the B fragments.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void scatterTile(const f32x4& acc, uint64_t maskWord, uint32_t base,
-                                            uint32_t laneInGroup, const uint32_t* __restrict__ dstIndex,
-                                            float* __restrict__ P) {
-    const uint32_t shift = 4u * laneInGroup;
-    const uint32_t mine = (uint32_t)(maskWord >> shift) & 0xFu;
-    if (mine == 0) return;
-    const uint32_t before = __popcll(maskWord & ((1ull << shift) - 1ull));
-    const uint32_t* ip = dstIndex + base + before;
-    if (mine & 1u) P[*ip++] = acc[0];
-    if (mine & 2u) P[*ip++] = acc[1];
-    if (mine & 4u) P[*ip++] = acc[2];
-    if (mine & 8u) P[*ip] = acc[3];
+template <typename TileT> struct TileLoad;
+template <> struct TileLoad<uint16_t> {
+    typedef uint32_t raw __attribute__((ext_vector_type(2)));
+    static constexpr uint32_t kNull = 0xFFFFu;
+    static __device__ __forceinline__ uint32_t get(const raw& v, int i) {
+        const uint32_t w = i < 2 ? v[0] : v[1];
+        return (i & 1) ? (w >> 16) : (w & 0xFFFFu);
+    }
+};
+template <> struct TileLoad<uint32_t> {
+    typedef u32x4 raw;
+    static constexpr uint32_t kNull = 0xFFFFFFFFu;
+    static __device__ __forceinline__ uint32_t get(const raw& v, int i) { return v[i]; }
+};
+
+template <typename TileT>
+__device__ __forceinline__ typename TileLoad<TileT>::raw loadTile(const TileT* __restrict__ tiles,
+                                                                  uint32_t block, uint32_t lane) {
+    return *reinterpret_cast<const typename TileLoad<TileT>::raw*>(tiles + (size_t)block * 256u + lane * 4u);
+}
+
+template <typename TileT>
+__device__ __forceinline__ void scatterTile(const f32x4& acc, const typename TileLoad<TileT>::raw& tile,
+                                            const uint32_t (&rowBase)[4], float* __restrict__ P) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t off = TileLoad<TileT>::get(tile, i);
+        if (off != TileLoad<TileT>::kNull) P[rowBase[i] + off] = acc[i];
+    }
 }
 
 template <int MODE>
@@ -120,16 +141,20 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f3
 }
 
 // ---------------------------------------------------------------------------
-// dense-block kernel, 16-bit operands.  KS = K/32 when known at compile time
-// (A fragments of the whole panel live in registers), 0 = run-time K loop.
+// dense-block kernel, 16-bit operands.
+//   KS = K/32 when known at compile time: the panel's A fragments live in
+//   registers for the whole item, and the item's blocks are processed NB at a
+//   time with every load of the batch (B fragments + destination tiles) issued
+//   before the first MFMA - one memory round trip per batch instead of one per
+//   block (the kernel is latency-bound, not bandwidth-bound, at L2-resident sizes).
+//   KS = 0: run-time K loop (any multiple of 32).
 // ---------------------------------------------------------------------------
-template <int KS, int MODE>
+template <int KS, int NB, int MODE, typename TileT>
 __global__ void __launch_bounds__(kThreads)
 denseBlocks16(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, uint32_t K,
-              const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ blockCols,
-              const uint64_t* __restrict__ blockMask, const uint32_t* __restrict__ blockBase,
-              const uint32_t* __restrict__ dstIndex, const DenseItem* __restrict__ items,
-              uint32_t numItems, float* __restrict__ P) {
+              const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ panelRowBase,
+              const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
+              const DenseItem* __restrict__ items, uint32_t numItems, float* __restrict__ P) {
     const uint32_t wg = xcdContiguous(blockIdx.x, gridDim.x);
     const uint32_t itemId = wg * kWavesPerWG + (threadIdx.x >> 6);
     if (itemId >= numItems) return;
@@ -139,37 +164,47 @@ denseBlocks16(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16
     const uint32_t g = lane >> 4;    // k group inside a 32-deep step / accumulator row group
 
     const uint16_t* aRow = A16 + (size_t)panelRows[item.panel * 16u + r] * K + g * 8u;
+    uint32_t rowBase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowBase[i] = panelRowBase[item.panel * 16u + 4u * g + i];
+    const uint32_t end = item.first + item.count;
 
     if constexpr (KS > 0) {
         u32x4 a[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const u32x4*>(aRow + s * 32);
 
-        for (uint32_t b = item.first; b < item.first + item.count; ++b) {
-            const uint16_t* bCol = B16 + (size_t)blockCols[b * 16u + r] * K + g * 8u;
-            u32x4 bf[KS];
+        for (uint32_t b0 = item.first; b0 < end; b0 += NB) {
+            u32x4 bf[NB][KS];
+            typename TileLoad<TileT>::raw tile[NB];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) bf[s] = *reinterpret_cast<const u32x4*>(bCol + s * 32);
-            const uint64_t maskWord = blockMask[b * 4u + g];
-            const uint32_t base = blockBase[b * 4u + g];
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < NB; ++n) {
+                const uint32_t b = min(b0 + n, end - 1u);  // tail of the batch re-reads the last block
+                const uint16_t* bCol = B16 + (size_t)blockCols[b * 16u + r] * K + g * 8u;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) acc = mfma16<MODE>(a[s], bf[s], acc);
-            scatterTile(acc, maskWord, base, r, dstIndex, P);
+                for (int s = 0; s < KS; ++s) bf[n][s] = *reinterpret_cast<const u32x4*>(bCol + s * 32);
+                tile[n] = loadTile<TileT>(tiles, b, lane);
+            }
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acc = mfma16<MODE>(a[s], bf[n][s], acc);
+                if (b0 + n < end) scatterTile<TileT>(acc, tile[n], rowBase, P);
+            }
         }
     } else {
         const uint32_t steps = K >> 5;
-        for (uint32_t b = item.first; b < item.first + item.count; ++b) {
+        for (uint32_t b = item.first; b < end; ++b) {
             const uint16_t* bCol = B16 + (size_t)blockCols[b * 16u + r] * K + g * 8u;
-            const uint64_t maskWord = blockMask[b * 4u + g];
-            const uint32_t base = blockBase[b * 4u + g];
+            const typename TileLoad<TileT>::raw tile = loadTile<TileT>(tiles, b, lane);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (uint32_t s = 0; s < steps; ++s) {
                 const u32x4 av = *reinterpret_cast<const u32x4*>(aRow + s * 32u);
                 const u32x4 bv = *reinterpret_cast<const u32x4*>(bCol + s * 32u);
                 acc = mfma16<MODE>(av, bv, acc);
             }
-            scatterTile(acc, maskWord, base, r, dstIndex, P);
+            scatterTile<TileT>(acc, tile, rowBase, P);
         }
     }
 }
@@ -181,12 +216,12 @@ denseBlocks16(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16
 // group g supplies k = 16t + 4g + j.  Chain order of k: for t, for j, for g.
 // (CPU twin: oracle_dense_f32_twin.)
 // ---------------------------------------------------------------------------
+template <typename TileT>
 __global__ void __launch_bounds__(kThreads)
 denseBlocks32(const float* __restrict__ A, const float* __restrict__ B, uint32_t K,
-              const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ blockCols,
-              const uint64_t* __restrict__ blockMask, const uint32_t* __restrict__ blockBase,
-              const uint32_t* __restrict__ dstIndex, const DenseItem* __restrict__ items,
-              uint32_t numItems, float* __restrict__ P) {
+              const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ panelRowBase,
+              const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
+              const DenseItem* __restrict__ items, uint32_t numItems, float* __restrict__ P) {
     const uint32_t wg = xcdContiguous(blockIdx.x, gridDim.x);
     const uint32_t itemId = wg * kWavesPerWG + (threadIdx.x >> 6);
     if (itemId >= numItems) return;
@@ -195,11 +230,13 @@ denseBlocks32(const float* __restrict__ A, const float* __restrict__ B, uint32_t
     const uint32_t r = lane & 15u;
     const uint32_t g = lane >> 4;
     const float* aRow = A + (size_t)panelRows[item.panel * 16u + r] * K + g * 4u;
+    uint32_t rowBase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowBase[i] = panelRowBase[item.panel * 16u + 4u * g + i];
     const uint32_t steps = K >> 4;
     for (uint32_t b = item.first; b < item.first + item.count; ++b) {
         const float* bCol = B + (size_t)blockCols[b * 16u + r] * K + g * 4u;
-        const uint64_t maskWord = blockMask[b * 4u + g];
-        const uint32_t base = blockBase[b * 4u + g];
+        const typename TileLoad<TileT>::raw tile = loadTile<TileT>(tiles, b, lane);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (uint32_t t = 0; t < steps; ++t) {
             const f32x4 av = *reinterpret_cast<const f32x4*>(aRow + t * 16u);
@@ -209,7 +246,7 @@ denseBlocks32(const float* __restrict__ A, const float* __restrict__ B, uint32_t
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc, 0, 0, 0);
         }
-        scatterTile(acc, maskWord, base, r, dstIndex, P);
+        scatterTile<TileT>(acc, tile, rowBase, P);
     }
 }
 

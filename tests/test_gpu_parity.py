@@ -63,7 +63,14 @@ def check_case(eng, oracle, rows, cols, ro, ci, K, alpha, delta, mode, row_mode=
     assert not np.isnan(got).any(), "some stored entry was never written"
     want_cpu = oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B)
     bad, first = oracle.check_data(want_cpu, got)
-    assert bad == 0, f"{bad} entries fail the reference tolerance (first {first})"
+    if mode == 1 and K < 512:
+        # bf16 operands (8-bit significand) are an explicit opt-in: on U[0,2) data the
+        # 1e-3 test only holds once K averages the operand rounding away (SURVEY.md
+        # appendix B).  Below that, bound the error by the operand rounding itself.
+        rel = np.abs(got - want_cpu) / np.maximum(np.abs(want_cpu), 1e-3)
+        assert rel.max() < 2.0 ** -7, f"bf16 relative error {rel.max()}"
+    else:
+        assert bad == 0, f"{bad} entries fail the reference tolerance (first {first})"
     twin, flags, model = expected_twin(oracle, pipe, K, ro, ci, A, B, mode)
     if mode == 2:
         assert np.array_equal(got.view(np.uint32), twin.view(np.uint32)), "F32 mode is not bit exact"
