@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "plan_pack.hpp"
 #include "sddmm_kernels.hpp"
 
 using bsmr::DenseItem;
@@ -25,20 +26,23 @@ using bsmr::SparseItem;
 struct bsmr_plan {
     int device = 0;
     uint32_t M = 0, N = 0, nnz = 0, numPanels = 0;
+    uint32_t H = 1;  // row panels per group of the dense path
 
-    // device-resident metadata
-    uint32_t* panelRows = nullptr;   // [numPanels*16] original row per panel row (padding -> a valid row)
-    uint32_t* blockCols = nullptr;   // [numBlocks*16] column per tile column (padding -> column 0)
-    uint32_t* panelRowBase = nullptr; // [numPanels*16] CSR offset that the tile offsets of a panel row add to
-    uint16_t* tiles16 = nullptr;     // [numBlocks*256] lane-major row-relative destinations, 0xFFFF = none
-    uint32_t* tiles32 = nullptr;     // same with 32-bit offsets (only when some row has >= 65535 entries)
+    // device-resident metadata (host layout: csrc/plan_pack.hpp)
+    uint32_t* panelRows = nullptr;
+    uint32_t* groupRows = nullptr;
+    uint32_t* groupRowBase = nullptr;
+    uint32_t* blockCols = nullptr;
+    uint16_t* tiles16 = nullptr;
+    uint32_t* tiles32 = nullptr;
+    uint8_t* blockMask = nullptr;
     DenseItem* denseItems = nullptr;
-    uint32_t* entryCol = nullptr;    // [numSparseEntries]
-    uint32_t* entryDst = nullptr;    // [numSparseEntries] CSR index
-    uint8_t* entryRow = nullptr;     // [numSparseEntries] row inside the panel
+    uint32_t* entryCol = nullptr;
+    uint32_t* entryDst = nullptr;
+    uint8_t* entryRow = nullptr;
     SparseItem* sparseItems = nullptr;
 
-    uint64_t numBlocks = 0, numDenseEntries = 0, numSparseEntries = 0;
+    uint64_t numBlocks = 0, numTiles = 0, unionColumns = 0, numDenseEntries = 0, numSparseEntries = 0;
     uint32_t numDenseItems = 0, numSparseItems = 0;
     uint64_t indexBytes = 0;
 
@@ -48,6 +52,7 @@ struct bsmr_plan {
     uint32_t reservedK = 0;
 
     int sparseLpe = 8;
+    int denseBatch = 0;  // blocks per LDS batch for K <= 128 (0 = default)
 };
 
 namespace {
@@ -96,8 +101,8 @@ int envInt(const char* name, int fallback) {
 }
 
 void freePlanDevice(bsmr_plan* p) {
-    void* ptrs[] = {p->panelRows, p->blockCols, p->panelRowBase, p->tiles16, p->tiles32,
-                    p->denseItems, p->entryCol, p->entryDst, p->entryRow, p->sparseItems,
+    void* ptrs[] = {p->panelRows, p->groupRows, p->groupRowBase, p->blockCols, p->tiles16, p->tiles32,
+                    p->blockMask, p->denseItems, p->entryCol, p->entryDst, p->entryRow, p->sparseItems,
                     p->A16, p->B16};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -119,20 +124,38 @@ int launchConvert(const bsmr_plan* p, uint32_t K, const float* A, const float* B
     return BSMR_OK;
 }
 
-// KS = K/32 (0 = run-time loop), NB = blocks whose loads are batched: KS*NB*4 B-fragment
-// registers per lane, kept at 64 so that several waves per SIMD stay resident.
+// LDS-staged dense kernel for K = 32*KS: KS, H (panels per group) and NB (blocks
+// per workgroup batch) are compile-time.  LDS = 2 * NB * KS KiB.
+template <int KS, int H, int NB, int MODE, typename TileT>
+int launchGroupsT(const bsmr_plan* p, const uint16_t* A16, const uint16_t* B16, const TileT* tiles, float* P,
+                  hipStream_t s) {
+    auto kernel = bsmr::denseGroups<KS, H, NB, MODE, TileT>;
+    const size_t lds = (size_t)2 * NB * 1024u * KS;  // double-buffered batch of NB blocks
+    static bool raised = false;  // per instantiation
+    if (lds > 64 * 1024 && !raised) {
+        BSMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(p->numDenseItems), dim3(bsmr::kThreads), lds, s, A16, B16, p->groupRows,
+                       p->groupRowBase, p->blockCols, tiles, p->blockMask, p->denseItems, P);
+    BSMR_HIP(hipGetLastError());
+    return BSMR_OK;
+}
+
+template <int KS, int H, int NB, int MODE>
+int launchGroups(const bsmr_plan* p, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+    return p->tiles16 ? launchGroupsT<KS, H, NB, MODE, uint16_t>(p, A16, B16, p->tiles16, P, s)
+                      : launchGroupsT<KS, H, NB, MODE, uint32_t>(p, A16, B16, p->tiles32, P, s);
+}
+
 template <int KS, int NB, int MODE>
-void launchDense16KS(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
-                     hipStream_t s) {
-    const uint32_t wgs = gridFor((p->numDenseItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG);
-    if (p->tiles16)
-        hipLaunchKernelGGL((bsmr::denseBlocks16<KS, NB, MODE, uint16_t>), dim3(wgs), dim3(bsmr::kThreads), 0,
-                           s, A16, B16, K, p->panelRows, p->panelRowBase, p->blockCols, p->tiles16,
-                           p->denseItems, p->numDenseItems, P);
-    else
-        hipLaunchKernelGGL((bsmr::denseBlocks16<KS, NB, MODE, uint32_t>), dim3(wgs), dim3(bsmr::kThreads), 0,
-                           s, A16, B16, K, p->panelRows, p->panelRowBase, p->blockCols, p->tiles32,
-                           p->denseItems, p->numDenseItems, P);
+int launchGroupsH(const bsmr_plan* p, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+    switch (p->H) {
+    case 1: return launchGroups<KS, 1, NB, MODE>(p, A16, B16, P, s);
+    case 2: return launchGroups<KS, 2, NB, MODE>(p, A16, B16, P, s);
+    default: return launchGroups<KS, 4, NB, MODE>(p, A16, B16, P, s);
+    }
 }
 
 template <int MODE>
@@ -140,13 +163,23 @@ int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uin
                   hipStream_t s) {
     if (p->numDenseItems == 0) return BSMR_OK;
     switch (K) {
-    case 32: launchDense16KS<1, 8, MODE>(p, K, A16, B16, P, s); break;
-    case 64: launchDense16KS<2, 8, MODE>(p, K, A16, B16, P, s); break;
-    case 128: launchDense16KS<4, 4, MODE>(p, K, A16, B16, P, s); break;
-    case 256: launchDense16KS<8, 2, MODE>(p, K, A16, B16, P, s); break;
-    case 512: launchDense16KS<16, 1, MODE>(p, K, A16, B16, P, s); break;
-    default: launchDense16KS<0, 1, MODE>(p, K, A16, B16, P, s); break;
+    case 32: return launchGroupsH<1, 16, MODE>(p, A16, B16, P, s);
+    case 64: return launchGroupsH<2, 8, MODE>(p, A16, B16, P, s);
+    case 128: return p->denseBatch == 8 ? launchGroupsH<4, 8, MODE>(p, A16, B16, P, s)
+                                        : launchGroupsH<4, 4, MODE>(p, A16, B16, P, s);
+    case 256: return launchGroupsH<8, 4, MODE>(p, A16, B16, P, s);
+    case 512: return launchGroupsH<16, 2, MODE>(p, A16, B16, P, s);
+    default: break;
     }
+    const uint32_t wgs = (p->numDenseItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
+    if (p->tiles16)
+        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint16_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A16,
+                           B16, K, p->H, p->groupRows, p->groupRowBase, p->blockCols, p->tiles16, p->blockMask,
+                           p->denseItems, p->numDenseItems, P);
+    else
+        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint32_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A16,
+                           B16, K, p->H, p->groupRows, p->groupRowBase, p->blockCols, p->tiles32, p->blockMask,
+                           p->denseItems, p->numDenseItems, P);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -154,15 +187,15 @@ int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uin
 int launchDense32(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P,
                   hipStream_t s) {
     if (p->numDenseItems == 0) return BSMR_OK;
-    const uint32_t wgs = gridFor((p->numDenseItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG);
+    const uint32_t wgs = (p->numDenseItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
     if (p->tiles16)
-        hipLaunchKernelGGL(bsmr::denseBlocks32<uint16_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           p->panelRows, p->panelRowBase, p->blockCols, p->tiles16, p->denseItems,
-                           p->numDenseItems, P);
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint16_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, p->H,
+                           p->groupRows, p->groupRowBase, p->blockCols, p->tiles16, p->blockMask,
+                           p->denseItems, p->numDenseItems, P);
     else
-        hipLaunchKernelGGL(bsmr::denseBlocks32<uint32_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           p->panelRows, p->panelRowBase, p->blockCols, p->tiles32, p->denseItems,
-                           p->numDenseItems, P);
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint32_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, p->H,
+                           p->groupRows, p->groupRowBase, p->blockCols, p->tiles32, p->blockMask,
+                           p->denseItems, p->numDenseItems, P);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -353,103 +386,15 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
     if (st != BSMR_OK) return st;
 
     try {
-        // ---- host-side packing -------------------------------------------
-        std::vector<uint32_t> panelRows((size_t)P * 16);
-        for (size_t i = 0; i < panelRows.size(); ++i) {
-            const uint32_t row = i < d->num_nonzero_rows ? d->reordered_rows[i] : d->reordered_rows[0];
-            if (row >= d->M) return BSMR_ERR_BAD_PLAN;
-            panelRows[i] = row;
-        }
-        for (uint32_t p = 0; p < P; ++p)
-            if (d->block_offsets[p + 1] < d->block_offsets[p] ||
-                d->sparse_value_offsets[p + 1] < d->sparse_value_offsets[p])
-                return BSMR_ERR_BAD_PLAN;
+        bsmr::PackOptions opt;
+        opt.group = envInt("BSMR_DENSE_GROUP", 0);
+        opt.blocksPerItem = envInt("BSMR_DENSE_BLOCKS_PER_WG", 32);
+        opt.sparsePerItem = envInt("BSMR_SPARSE_ENTRIES_PER_WG", 256);
+        opt.forceWideTiles = envInt("BSMR_FORCE_TILE32", 0) != 0;
+        bsmr::PackedPlan pk;
+        st = bsmr::packPlan(d, opt, pk);
+        if (st != BSMR_OK) return st;
 
-        std::vector<uint32_t> blockCols(numBlocks * 16);
-        for (size_t i = 0; i < blockCols.size(); ++i) {
-            const uint32_t c = d->dense_cols[i];
-            if (c > d->N) return BSMR_ERR_BAD_PLAN;
-            blockCols[i] = c == d->N ? 0u : c;  // padding column: any readable column, its outputs are masked
-        }
-
-        // Destination tiles.  rowBase of a panel row = smallest CSR index among its
-        // dense entries (= the row's CSR offset when the whole row is dense); tile
-        // element [4*lane + i] = CSR index - rowBase for accumulator register i of
-        // `lane` (tile row 4*(lane>>4)+i, tile column lane&15).
-        std::vector<uint32_t> panelRowBase((size_t)P * 16, 0);
-        uint64_t numDenseEntries = 0;
-        uint32_t maxOffset = 0;
-        for (uint32_t p = 0; p < P; ++p) {
-            uint32_t lo[16], hi[16];
-            for (int r = 0; r < 16; ++r) { lo[r] = 0xFFFFFFFFu; hi[r] = 0; }
-            for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b) {
-                const uint32_t* tile = d->block_values + b * 256;
-                for (uint32_t i = 0; i < 256; ++i) {
-                    const uint32_t v = tile[i];
-                    if (v == 0xFFFFFFFFu) continue;
-                    if (v >= d->nnz) return BSMR_ERR_BAD_PLAN;
-                    ++numDenseEntries;
-                    lo[i >> 4] = std::min(lo[i >> 4], v);
-                    hi[i >> 4] = std::max(hi[i >> 4], v);
-                }
-            }
-            for (int r = 0; r < 16; ++r) {
-                if (lo[r] == 0xFFFFFFFFu) continue;
-                panelRowBase[(size_t)p * 16 + r] = lo[r];
-                maxOffset = std::max(maxOffset, hi[r] - lo[r]);
-            }
-        }
-        const bool wideTiles = maxOffset >= 0xFFFFu || envInt("BSMR_FORCE_TILE32", 0) != 0;
-        std::vector<uint16_t> tiles16(wideTiles ? 0 : numBlocks * 256);
-        std::vector<uint32_t> tiles32(wideTiles ? numBlocks * 256 : 0);
-        for (uint32_t p = 0; p < P; ++p)
-            for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b) {
-                const uint32_t* tile = d->block_values + b * 256;
-                for (uint32_t lane = 0; lane < 64; ++lane)
-                    for (uint32_t i = 0; i < 4; ++i) {
-                        const uint32_t row = 4 * (lane >> 4) + i, col = lane & 15u;
-                        const uint32_t v = tile[row * 16 + col];
-                        const uint32_t off = v == 0xFFFFFFFFu ? 0xFFFFFFFFu : v - panelRowBase[(size_t)p * 16 + row];
-                        if (wideTiles) tiles32[b * 256 + lane * 4 + i] = off;
-                        else tiles16[b * 256 + lane * 4 + i] = (uint16_t)off;
-                    }
-            }
-
-        std::vector<uint32_t> entryCol(numSparse), entryDst(numSparse);
-        std::vector<uint8_t> entryRow(numSparse);
-        for (uint64_t i = 0; i < numSparse; ++i) {
-            if (d->sparse_col_indices[i] >= d->N || d->sparse_values[i] >= d->nnz ||
-                d->sparse_relative_rows[i] >= 16)
-                return BSMR_ERR_BAD_PLAN;
-            entryCol[i] = d->sparse_col_indices[i];
-            entryDst[i] = d->sparse_values[i];
-            entryRow[i] = (uint8_t)d->sparse_relative_rows[i];
-        }
-        if (numDenseEntries + numSparse != d->nnz) return BSMR_ERR_BAD_PLAN;
-
-        // ---- work lists ----------------------------------------------------
-        // dense: runs of `chunk` blocks of one panel per wave; small enough that
-        // the chip (256 CUs x 4 SIMDs x several waves) is covered, large enough
-        // that the panel's A fragments are amortised.
-        int chunk = envInt("BSMR_DENSE_CHUNK", 0);
-        if (chunk <= 0) {
-            const uint64_t targetWaves = 256ull * 4 * 6;
-            chunk = (int)std::max<uint64_t>(4, std::min<uint64_t>(16, numBlocks / targetWaves));
-            chunk = (chunk + 3) & ~3;  // whole load batches (NB divides 8) for K <= 128
-        }
-        std::vector<DenseItem> denseItems;
-        for (uint32_t p = 0; p < P; ++p)
-            for (uint32_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; b += chunk)
-                denseItems.push_back(DenseItem{p, b, std::min<uint32_t>(chunk, d->block_offsets[p + 1] - b), 0});
-
-        const uint32_t perWG = (uint32_t)std::max(32, envInt("BSMR_SPARSE_ENTRIES_PER_WG", 256));
-        std::vector<SparseItem> sparseItems;
-        for (uint32_t p = 0; p < P; ++p)
-            for (uint32_t s = d->sparse_value_offsets[p]; s < d->sparse_value_offsets[p + 1]; s += perWG)
-                sparseItems.push_back(
-                    SparseItem{p, s, std::min<uint32_t>(perWG, d->sparse_value_offsets[p + 1] - s), 0});
-
-        // ---- upload ----------------------------------------------------------
         bsmr_plan* p = new (std::nothrow) bsmr_plan;
         if (!p) return BSMR_ERR_OOM;
         p->device = device;
@@ -457,24 +402,30 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         p->N = d->N;
         p->nnz = d->nnz;
         p->numPanels = P;
-        p->numBlocks = numBlocks;
-        p->numDenseEntries = numDenseEntries;
-        p->numSparseEntries = numSparse;
-        p->numDenseItems = (uint32_t)denseItems.size();
-        p->numSparseItems = (uint32_t)sparseItems.size();
+        p->H = pk.H;
+        p->numBlocks = pk.numBlocks;
+        p->numTiles = pk.numTiles;
+        p->unionColumns = pk.unionColumns;
+        p->numDenseEntries = pk.numDenseEntries;
+        p->numSparseEntries = pk.numSparseEntries;
+        p->numDenseItems = (uint32_t)pk.denseItems.size();
+        p->numSparseItems = (uint32_t)pk.sparseItems.size();
         p->sparseLpe = envInt("BSMR_SPARSE_LPE", 8);
         if (p->sparseLpe != 4 && p->sparseLpe != 8 && p->sparseLpe != 16) p->sparseLpe = 8;
+        p->denseBatch = envInt("BSMR_DENSE_BATCH", 0);
 
-        st = upload(p->panelRows, panelRows, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->blockCols, blockCols, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->panelRowBase, panelRowBase, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->tiles16, tiles16, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->tiles32, tiles32, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->denseItems, denseItems, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->entryCol, entryCol, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->entryDst, entryDst, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->entryRow, entryRow, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->sparseItems, sparseItems, p->indexBytes);
+        st = upload(p->panelRows, pk.panelRows, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->groupRows, pk.groupRows, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->groupRowBase, pk.groupRowBase, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->blockCols, pk.blockCols, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->tiles16, pk.tiles16, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->tiles32, pk.tiles32, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->blockMask, pk.blockMask, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->denseItems, pk.denseItems, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->entryCol, pk.entryCol, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->entryDst, pk.entryDst, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->entryRow, pk.entryRow, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->sparseItems, pk.sparseItems, p->indexBytes);
         if (st != BSMR_OK) {
             freePlanDevice(p);
             delete p;
@@ -506,6 +457,9 @@ int bsmr_plan_get_stats(const bsmr_plan* p, bsmr_plan_stats* out) {
     out->dense_work_items = p->numDenseItems;
     out->sparse_work_items = p->numSparseItems;
     out->device_index_bytes = p->indexBytes;
+    out->group_size = p->H;
+    out->num_dense_tiles = p->numTiles;
+    out->union_columns = p->unionColumns;
     return BSMR_OK;
 }
 

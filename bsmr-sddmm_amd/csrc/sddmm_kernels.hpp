@@ -3,24 +3,34 @@
 // What they compute is what the reference's live kernels compute
 // (src/sddmmKernel.cu:213-351 dense blocks, :1994-2104 sparse residue): for every
 // stored entry e = (i, j) of S,  P[e] = sum_k A[i,k] * B[k,j].  How they do it is
-// designed for MI355X and shares nothing with the CUDA code:
+// designed for MI355X and shares nothing with the CUDA code.
 //
-//  * B is column-major, so a "column" is K contiguous elements.  The MFMA
-//    16x16x32 operand maps put element j of lane l at A[row l&15][k = 8(l>>4)+j]
-//    and B[k = 8(l>>4)+j][col l&15]: for both operands a lane's 8 elements are
-//    16 contiguous bytes of one (gathered) row / column.  Fragments are therefore
-//    loaded straight from global memory with one global_load_dwordx4 per lane and
-//    K step - no LDS staging, no transposes, no bank conflicts.
-//  * One wave owns one row panel x a run of dense blocks; the panel's A
-//    fragments stay in registers across the run.
-//  * The sparsity mask and the destinations are one tile of 256 row-relative
-//    16-bit offsets per block, stored in accumulator (lane-major) order: 8 bytes
-//    per lane, loaded together with the B fragments (the reference stores a 1 KiB
-//    row-major tile of absolute 32-bit indices per block).
-//  * The residual sparse path splits K over LPE lanes per entry (coalesced 16-byte
-//    loads of the B column), takes the panel's A rows from LDS, and reduces with
-//    a butterfly; it is exact fp32 with a defined summation order (bit-level CPU
-//    twin: oracle/sddmm_oracle.c oracle_sparse_twin).
+// Dense path (denseGroups):
+//  * Measured on MI355X the dense path is bound by the per-CU vector-memory
+//    front end (TA), not by MFMA (idle > 90 %) nor by L2: gathering B columns is
+//    what costs.  So the plan groups H consecutive row panels (16*H rows) into a
+//    row GROUP and takes the union of their dense columns; a gathered 16-column
+//    B block is then multiplied against all H panels (H MFMA tiles).  MFMA work
+//    grows, B traffic shrinks (nips-like, H=4: 88 MB -> 46 MB).
+//  * B is column-major: a column is K contiguous elements.  A 16-column block is
+//    gathered with LDS-DMA (global_load_lds_dwordx4): each wave-instruction
+//    moves 1 KiB made of whole 128-byte-line runs of columns (fragment-shaped
+//    register loads - 16 rows x 64 B per instruction - cost twice the TA time).
+//    The LDS image is lane-linear; the 16-byte pieces of a column are
+//    XOR-swizzled on the SOURCE address so that the MFMA fragment reads
+//    (ds_read_b128, 16 lanes = 16 columns at one k offset) are conflict-free.
+//  * The four waves of a workgroup split a group's work by panel: each wave
+//    keeps its own panel's A fragments in registers; B blocks are shared via LDS.
+//  * Mask + destinations: per (block, panel) one tile of 256 row-relative 16-bit
+//    offsets in accumulator (lane-major) order, 0xFFFF = no entry: 8 bytes per
+//    lane, independent of anything the wave computes (the reference stores a
+//    1 KiB row-major tile of absolute 32-bit indices per block).  Tiles that
+//    hold no entry are skipped through a per-block bit mask.
+//
+// Sparse residue (sparseEntries): K split over LPE lanes per entry (coalesced
+// 16-byte loads of the B column), A rows from LDS, butterfly reduction; exact
+// fp32 with a defined summation order (bit-level CPU twin:
+// oracle/sddmm_oracle.c oracle_sparse_twin).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -36,10 +46,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWave = 64;
 constexpr int kThreads = 256;           // 4 waves per workgroup
 constexpr int kWavesPerWG = kThreads / kWave;
+constexpr int kMaxGroup = 4;            // row panels per group (H)
 
-// One unit of dense work: blocks [first, first+count) (global block ids) of `panel`.
+// One unit of dense work: blocks [first, first+count) (global block ids) of row group `group`.
 struct DenseItem {
-    uint32_t panel;
+    uint32_t group;
     uint32_t first;
     uint32_t count;
     uint32_t pad;
@@ -55,7 +66,7 @@ struct SparseItem {
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
 // L2).  Give each XCD a contiguous slice of the work list so that neighbouring
-// items - consecutive blocks of one panel, consecutive panels of one cluster,
+// items - consecutive blocks of one group, consecutive groups of one cluster,
 // which share B columns - hit the same L2.  Speed only; any placement is correct.
 __device__ __forceinline__ uint32_t xcdContiguous(uint32_t wg, uint32_t numWG) {
     return (numWG & 7u) == 0 ? (wg & 7u) * (numWG >> 3) + (wg >> 3) : wg;
@@ -92,12 +103,9 @@ convertOperands(const float* __restrict__ A, uint64_t nA8, const float* __restri
 // ---------------------------------------------------------------------------
 // masked write-back of one 16x16 accumulator tile
 //   lane l, register i  <->  tile row 4*(l>>4)+i, tile column l&15
-//   The plan stores, per block, 256 destinations in exactly that (lane-major)
-//   order: element [4*l + i] = CSR index of the entry minus the CSR offset of its
-//   row (`rowBase`), or all-ones where S has no entry.  16-bit offsets serve every
-//   matrix whose rows hold < 65535 entries (8 bytes per lane and block); the
-//   32-bit form is the fallback.  The load does not depend on anything computed
-//   by the wave, so it is issued together with the B fragments.
+//   tile element [4*l + i] = CSR index of the entry minus `rowBase` of its row,
+//   or all-ones where S has no entry.  16-bit offsets serve every matrix whose
+//   rows hold < 65535 entries; the 32-bit form is the fallback.
 // ---------------------------------------------------------------------------
 template <typename TileT> struct TileLoad;
 template <> struct TileLoad<uint16_t> {
@@ -116,13 +124,13 @@ template <> struct TileLoad<uint32_t> {
 
 template <typename TileT>
 __device__ __forceinline__ typename TileLoad<TileT>::raw loadTile(const TileT* __restrict__ tiles,
-                                                                  uint32_t block, uint32_t lane) {
-    return *reinterpret_cast<const typename TileLoad<TileT>::raw*>(tiles + (size_t)block * 256u + lane * 4u);
+                                                                  size_t tileId, uint32_t lane) {
+    return *reinterpret_cast<const typename TileLoad<TileT>::raw*>(tiles + tileId * 256u + lane * 4u);
 }
 
 template <typename TileT>
 __device__ __forceinline__ void scatterTile(const f32x4& acc, const typename TileLoad<TileT>::raw& tile,
-                                            const uint32_t (&rowBase)[4], float* __restrict__ P) {
+                                            const uint32_t* rowBase, float* __restrict__ P) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t off = TileLoad<TileT>::get(tile, i);
@@ -141,63 +149,178 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f3
 }
 
 // ---------------------------------------------------------------------------
-// dense-block kernel, 16-bit operands.
-//   KS = K/32 when known at compile time: the panel's A fragments live in
-//   registers for the whole item, and the item's blocks are processed NB at a
-//   time with every load of the batch (B fragments + destination tiles) issued
-//   before the first MFMA - one memory round trip per batch instead of one per
-//   block (the kernel is latency-bound, not bandwidth-bound, at L2-resident sizes).
-//   KS = 0: run-time K loop (any multiple of 32).
+// dense kernel, 16-bit operands, K = 32*KS known at compile time (KS a power of 2).
+//
+// One workgroup = one DenseItem (a run of blocks of one row group).  The four
+// waves split the work as (panel h = wave % H, block subset = wave / H): a wave
+// keeps only ITS panel's A fragments in registers and multiplies them with every
+// block of its subset, so a gathered B block is shared by the H panels of the
+// group.  Blocks are processed in batches of NBW; the batch's B columns are
+// gathered cooperatively (all four waves issue LDS-DMA) into one half of a
+// double buffer while the previous batch is being multiplied out of the other.
+//
+// LDS image of a block: column c at c*2K bytes; its 16-byte piece w (k = 8w ..
+// 8w+7) sits at piece slot w ^ (c & SW), SW = min(15, pieces-1).  LDS-DMA writes
+// lane-linearly, so the swizzle is applied to the SOURCE address.  The MFMA
+// fragment of lane (c = l&15, g = l>>4) at K step s is piece 4s+g of column c:
+// the 16 lanes of a ds_read_b128 group hit 16 different 16-byte slots.
 // ---------------------------------------------------------------------------
-template <int KS, int NB, int MODE, typename TileT>
+template <int KS, int H, int NBW, int MODE, typename TileT>
 __global__ void __launch_bounds__(kThreads)
-denseBlocks16(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, uint32_t K,
-              const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ panelRowBase,
-              const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
-              const DenseItem* __restrict__ items, uint32_t numItems, float* __restrict__ P) {
-    const uint32_t wg = xcdContiguous(blockIdx.x, gridDim.x);
-    const uint32_t itemId = wg * kWavesPerWG + (threadIdx.x >> 6);
-    if (itemId >= numItems) return;
-    const DenseItem item = items[itemId];
+denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
+            const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ groupRowBase,
+            const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
+            const uint8_t* __restrict__ blockMask, const DenseItem* __restrict__ items, float* __restrict__ P) {
+    constexpr uint32_t K = 32u * KS;
+    constexpr uint32_t PC = 4u * KS;                 // 16-byte pieces per column
+    constexpr uint32_t SW = PC - 1u < 15u ? PC - 1u : 15u;
+    constexpr uint32_t rowBytes = 2u * K;
+    constexpr uint32_t blkBytes = 16u * rowBytes;    // = KS KiB
+    constexpr uint32_t NSUB = kWavesPerWG / H;       // block subsets (waves per panel)
+    constexpr uint32_t MINE = (NBW + NSUB - 1) / NSUB;  // blocks of a batch one wave multiplies
+    constexpr uint32_t CREG = (NBW + 3) / 4;         // registers holding the batch's column ids
+    constexpr uint32_t DMAS = (NBW * KS + kWavesPerWG - 1) / kWavesPerWG;  // DMA instructions per wave and batch
+    typedef typename TileLoad<TileT>::raw TileRaw;
+    static_assert(NBW <= 16 && (NBW & (NBW - 1)) == 0, "NBW must be a power of two <= 16");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [2][NBW][blkBytes]
+
+    const DenseItem item = items[xcdContiguous(blockIdx.x, gridDim.x)];
+    const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t r = lane & 15u;   // tile row for A, tile column for B and C
     const uint32_t g = lane >> 4;    // k group inside a 32-deep step / accumulator row group
-
-    const uint16_t* aRow = A16 + (size_t)panelRows[item.panel * 16u + r] * K + g * 8u;
-    uint32_t rowBase[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rowBase[i] = panelRowBase[item.panel * 16u + 4u * g + i];
+    const uint32_t h = wave % H, sub = wave / H;
+    const uint32_t rowSlot = item.group * (16u * H) + h * 16u;
     const uint32_t end = item.first + item.count;
+    const uint32_t numBatches = (item.count + NBW - 1) / NBW;
 
-    if constexpr (KS > 0) {
-        u32x4 a[KS];
+    // this wave's panel: A fragments (once per item) and CSR row offsets
+    u32x4 a[KS];
+    {
+        const uint16_t* aRow = A16 + (size_t)groupRows[rowSlot + r] * K + g * 8u;
 #pragma unroll
         for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const u32x4*>(aRow + s * 32);
+    }
+    uint32_t rowBase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowBase[i] = groupRowBase[rowSlot + 4u * g + i];
 
-        for (uint32_t b0 = item.first; b0 < end; b0 += NB) {
-            u32x4 bf[NB][KS];
-            typename TileLoad<TileT>::raw tile[NB];
+    // batch metadata: cols[q] of lane l = column (l & 15) of block b0 + 4q + (l >> 4);
+    // maskReg of lane l = tile mask of block b0 + (l % NBW) (0 past the end)
+    auto loadMeta = [&](uint32_t b0, uint32_t (&cols)[CREG], uint32_t& maskReg) {
 #pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const uint32_t b = min(b0 + n, end - 1u);  // tail of the batch re-reads the last block
-                const uint16_t* bCol = B16 + (size_t)blockCols[b * 16u + r] * K + g * 8u;
+        for (uint32_t q = 0; q < CREG; ++q)
+            cols[q] = blockCols[(size_t)min(b0 + 4u * q + g, end - 1u) * 16u + r];
+        const uint32_t mb = b0 + (lane & (NBW - 1u));
+        maskReg = mb < end ? (uint32_t)blockMask[mb] : 0u;
+    };
+    // this wave's share of the batch's gather: DMA instruction i = n*KS + j moves
+    // flat piece slots [64j, 64j+64) of block n
+    auto issueGather = [&](uint32_t buf, const uint32_t (&cols)[CREG]) {
+        uint8_t* base = lds + buf * (NBW * blkBytes);
 #pragma unroll
-                for (int s = 0; s < KS; ++s) bf[n][s] = *reinterpret_cast<const u32x4*>(bCol + s * 32);
-                tile[n] = loadTile<TileT>(tiles, b, lane);
+        for (uint32_t d = 0; d < DMAS; ++d) {
+            const uint32_t i = d * kWavesPerWG + wave;
+            if (NBW * KS % kWavesPerWG != 0 && i >= NBW * KS) break;
+            const uint32_t n = i / KS, j = i % KS;
+            const uint32_t f = 64u * j + lane;
+            const uint32_t col = f / PC, t = f % PC;
+            uint32_t cid = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < CREG; ++q) {  // n is wave-uniform: pick the register, then the lane
+                const uint32_t v = __shfl(cols[q], ((n & 3u) << 4) + col);
+                if ((n >> 2) == q) cid = v;
             }
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < KS; ++s) acc = mfma16<MODE>(a[s], bf[n][s], acc);
-                if (b0 + n < end) scatterTile<TileT>(acc, tile[n], rowBase, P);
-            }
+            const uint16_t* src = B16 + (size_t)cid * K + ((t ^ (col & SW)) << 3);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)src,
+                (__attribute__((address_space(3))) void*)(base + n * blkBytes + j * 1024u), 16, 0, 0);
         }
-    } else {
-        const uint32_t steps = K >> 5;
-        for (uint32_t b = item.first; b < end; ++b) {
-            const uint16_t* bCol = B16 + (size_t)blockCols[b * 16u + r] * K + g * 8u;
-            const typename TileLoad<TileT>::raw tile = loadTile<TileT>(tiles, b, lane);
+    };
+    // destination tiles of the blocks this wave multiplies (block n = sub + NSUB*m)
+    auto loadTiles = [&](uint32_t b0, uint32_t maskReg, TileRaw (&tile)[MINE]) {
+#pragma unroll
+        for (uint32_t m = 0; m < MINE; ++m) {
+            const uint32_t n = sub + NSUB * m;
+            const uint32_t mk = n < NBW ? (uint32_t)__builtin_amdgcn_readlane(maskReg, n & (NBW - 1u)) : 0u;
+            if (mk & (1u << h)) tile[m] = loadTile<TileT>(tiles, (size_t)(b0 + n) * H + h, lane);
+        }
+    };
+
+    uint32_t colsCur[CREG], colsNext[CREG];
+    uint32_t maskCur = 0, maskNext = 0;
+    TileRaw tileCur[MINE], tileNext[MINE];
+    loadMeta(item.first, colsCur, maskCur);
+    issueGather(0, colsCur);
+    loadTiles(item.first, maskCur, tileCur);
+    if (numBatches > 1) loadMeta(item.first + NBW, colsNext, maskNext);
+
+    for (uint32_t it = 0; it < numBatches; ++it) {
+        const uint32_t b0 = item.first + it * NBW;
+        // batch `it` has landed (every wave drains its own DMA, then all meet); the
+        // other buffer is free because every wave finished batch it-1 before arriving.
+        __syncthreads();
+        if (it + 1 < numBatches) {
+            issueGather((it + 1) & 1u, colsNext);
+            loadTiles(b0 + NBW, maskNext, tileNext);
+        }
+        uint32_t colsAfter[CREG];
+        uint32_t maskAfter = 0;
+        if (it + 2 < numBatches) loadMeta(b0 + 2 * NBW, colsAfter, maskAfter);
+
+        const uint8_t* buf = lds + (it & 1u) * (NBW * blkBytes);
+#pragma unroll
+        for (uint32_t m = 0; m < MINE; ++m) {
+            const uint32_t n = sub + NSUB * m;
+            if (n >= NBW) break;
+            const uint32_t mk = __builtin_amdgcn_readlane(maskCur, n & (NBW - 1u));
+            if (!(mk & (1u << h))) continue;  // wave-uniform: this panel has no entry in the block
+            const uint8_t* bCol = buf + n * blkBytes + r * rowBytes;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const u32x4 bv = *reinterpret_cast<const u32x4*>(bCol + (((4u * s + g) ^ (r & SW)) << 4));
+                acc = mfma16<MODE>(a[s], bv, acc);
+            }
+            scatterTile<TileT>(acc, tileCur[m], rowBase, P);
+        }
+#pragma unroll
+        for (uint32_t m = 0; m < MINE; ++m) tileCur[m] = tileNext[m];
+#pragma unroll
+        for (uint32_t q = 0; q < CREG; ++q) colsNext[q] = colsAfter[q];
+        maskCur = maskNext;
+        maskNext = maskAfter;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dense fallback, 16-bit operands, any K (multiple of 32): fragments straight
+// from global memory, run-time K loop.  One wave per DenseItem.
+// ---------------------------------------------------------------------------
+template <int MODE, typename TileT>
+__global__ void __launch_bounds__(kThreads)
+denseGroupsAnyK(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, uint32_t K, uint32_t H,
+                const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ groupRowBase,
+                const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
+                const uint8_t* __restrict__ blockMask, const DenseItem* __restrict__ items,
+                uint32_t numItems, float* __restrict__ P) {
+    const uint32_t itemId = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
+    if (itemId >= numItems) return;
+    const DenseItem item = items[itemId];
+    const uint32_t lane = threadIdx.x & 63u, r = lane & 15u, g = lane >> 4;
+    const uint32_t steps = K >> 5;
+    for (uint32_t b = item.first; b < item.first + item.count; ++b) {
+        const uint32_t mask = blockMask[b];
+        const uint16_t* bCol = B16 + (size_t)blockCols[(size_t)b * 16u + r] * K + g * 8u;
+        for (uint32_t h = 0; h < H; ++h) {
+            if (!(mask & (1u << h))) continue;
+            const uint32_t slot = item.group * 16u * H + h * 16u;
+            const uint16_t* aRow = A16 + (size_t)groupRows[slot + r] * K + g * 8u;
+            const typename TileLoad<TileT>::raw tile = loadTile<TileT>(tiles, (size_t)b * H + h, lane);
+            uint32_t rowBase[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rowBase[i] = groupRowBase[slot + 4u * g + i];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (uint32_t s = 0; s < steps; ++s) {
                 const u32x4 av = *reinterpret_cast<const u32x4*>(aRow + s * 32u);
@@ -210,43 +333,46 @@ denseBlocks16(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16
 }
 
 // ---------------------------------------------------------------------------
-// dense-block kernel, exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf
-// chain.  Lane (r, g) loads float4 chunks [16t + 4g, +4) of its row / column;
-// MFMA number (t, j) multiplies element j of every chunk, so inside it lane
-// group g supplies k = 16t + 4g + j.  Chain order of k: for t, for j, for g.
-// (CPU twin: oracle_dense_f32_twin.)
+// dense kernel, exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain.
+// Lane (r, g) loads float4 chunks [16t + 4g, +4) of its row / column; MFMA
+// number (t, j) multiplies element j of every chunk, so inside it lane group g
+// supplies k = 16t + 4g + j.  Chain order of k: for t, for j, for g.
+// (CPU twin: oracle_dense_f32_twin.)  One wave per DenseItem.
 // ---------------------------------------------------------------------------
 template <typename TileT>
 __global__ void __launch_bounds__(kThreads)
-denseBlocks32(const float* __restrict__ A, const float* __restrict__ B, uint32_t K,
-              const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ panelRowBase,
-              const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
-              const DenseItem* __restrict__ items, uint32_t numItems, float* __restrict__ P) {
-    const uint32_t wg = xcdContiguous(blockIdx.x, gridDim.x);
-    const uint32_t itemId = wg * kWavesPerWG + (threadIdx.x >> 6);
+denseGroupsF32(const float* __restrict__ A, const float* __restrict__ B, uint32_t K, uint32_t H,
+               const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ groupRowBase,
+               const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
+               const uint8_t* __restrict__ blockMask, const DenseItem* __restrict__ items,
+               uint32_t numItems, float* __restrict__ P) {
+    const uint32_t itemId = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
     if (itemId >= numItems) return;
     const DenseItem item = items[itemId];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t r = lane & 15u;
-    const uint32_t g = lane >> 4;
-    const float* aRow = A + (size_t)panelRows[item.panel * 16u + r] * K + g * 4u;
-    uint32_t rowBase[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rowBase[i] = panelRowBase[item.panel * 16u + 4u * g + i];
+    const uint32_t lane = threadIdx.x & 63u, r = lane & 15u, g = lane >> 4;
     const uint32_t steps = K >> 4;
     for (uint32_t b = item.first; b < item.first + item.count; ++b) {
-        const float* bCol = B + (size_t)blockCols[b * 16u + r] * K + g * 4u;
-        const typename TileLoad<TileT>::raw tile = loadTile<TileT>(tiles, b, lane);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (uint32_t t = 0; t < steps; ++t) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(aRow + t * 16u);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bCol + t * 16u);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc, 0, 0, 0);
+        const uint32_t mask = blockMask[b];
+        const float* bCol = B + (size_t)blockCols[(size_t)b * 16u + r] * K + g * 4u;
+        for (uint32_t h = 0; h < H; ++h) {
+            if (!(mask & (1u << h))) continue;
+            const uint32_t slot = item.group * 16u * H + h * 16u;
+            const float* aRow = A + (size_t)groupRows[slot + r] * K + g * 4u;
+            const typename TileLoad<TileT>::raw tile = loadTile<TileT>(tiles, (size_t)b * H + h, lane);
+            uint32_t rowBase[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rowBase[i] = groupRowBase[slot + 4u * g + i];
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (uint32_t t = 0; t < steps; ++t) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(aRow + t * 16u);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bCol + t * 16u);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc, 0, 0, 0);
+            }
+            scatterTile<TileT>(acc, tile, rowBase, P);
         }
-        scatterTile<TileT>(acc, tile, rowBase, P);
     }
 }
 

@@ -47,7 +47,8 @@ class PlanStats(C.Structure):
     _fields_ = [("num_row_panels", C.c_uint32), ("num_dense_blocks", C.c_uint64),
                 ("num_dense_entries", C.c_uint64), ("num_sparse_entries", C.c_uint64),
                 ("dense_work_items", C.c_uint64), ("sparse_work_items", C.c_uint64),
-                ("device_index_bytes", C.c_uint64)]
+                ("device_index_bytes", C.c_uint64), ("group_size", C.c_uint32),
+                ("num_dense_tiles", C.c_uint64), ("union_columns", C.c_uint64)]
 
 
 class Timing(C.Structure):

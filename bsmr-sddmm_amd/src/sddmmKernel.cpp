@@ -42,7 +42,7 @@ void sddmm_gpu(UIN M, UIN N, UIN K, const float* matrixA, const float* matrixB, 
     }
     bsmr_plan_stats s{};
     bsmr_plan_get_stats(rphm.plan(), &s);
-    logger.gridDim_dense_ = Dim3{static_cast<unsigned>((s.dense_work_items + 3) / 4), 1, 1};
+    logger.gridDim_dense_ = Dim3{static_cast<unsigned>(s.dense_work_items), 1, 1};
     logger.blockDim_dense_ = Dim3{256, 1, 1};
     logger.gridDim_sparse_ = Dim3{static_cast<unsigned>(s.sparse_work_items), 1, 1};
     logger.blockDim_sparse_ = Dim3{256, 1, 1};

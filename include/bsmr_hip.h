@@ -77,12 +77,15 @@ typedef struct bsmr_rphm_desc {
 
 typedef struct bsmr_plan_stats {
     uint32_t num_row_panels;
-    uint64_t num_dense_blocks;
+    uint64_t num_dense_blocks;    /* 16-column blocks of the grouped device format */
     uint64_t num_dense_entries;   /* nnz covered by the dense path  */
     uint64_t num_sparse_entries;  /* nnz covered by the sparse path */
     uint64_t dense_work_items;    /* waves launched by the dense kernel        */
     uint64_t sparse_work_items;   /* workgroups launched by the sparse kernel  */
     uint64_t device_index_bytes;  /* bytes of plan metadata resident in HBM    */
+    uint32_t group_size;          /* row panels whose dense columns share one B gather (1, 2, 4) */
+    uint64_t num_dense_tiles;     /* non-empty 16x16 (panel, block) tiles = MFMA tiles executed   */
+    uint64_t union_columns;       /* B columns gathered per SDDMM by the dense path               */
 } bsmr_plan_stats;
 
 /* Kernel timings of the last bsmr_sddmm_timed call, milliseconds per iteration. */

@@ -31,15 +31,19 @@ P = torch.zeros(csr.nnz, dtype=torch.float32, device=dev)
 s = torch.cuda.current_stream(dev).cuda_stream
 
 knobs = [{}]
-for c in (1, 2, 4, 8, 12, 16, 32):
-    knobs.append({"BSMR_DENSE_CHUNK": str(c)})
-for lpe in (4, 16):
-    knobs.append({"BSMR_SPARSE_LPE": str(lpe)})
-for e in (64, 128, 512, 1024):
-    knobs.append({"BSMR_SPARSE_ENTRIES_PER_WG": str(e)})
-knobs.append({"BSMR_FORCE_TILE32": "1"})
+for h in (1, 2, 4):
+    for bpw in (8, 16, 32):
+        for batch in (4, 8):
+            knobs.append({"BSMR_DENSE_GROUP": str(h), "BSMR_DENSE_BLOCKS_PER_WG": str(bpw), "BSMR_DENSE_BATCH": str(batch)})
+if "--sparse" in sys.argv:
+    knobs = [{}]
+    for lpe in (4, 8, 16):
+        for e in (64, 128, 256, 512, 1024):
+            knobs.append({"BSMR_SPARSE_LPE": str(lpe), "BSMR_SPARSE_ENTRIES_PER_WG": str(e)})
+ALL = ("BSMR_DENSE_GROUP", "BSMR_DENSE_BLOCKS_PER_WG", "BSMR_DENSE_BATCH", "BSMR_SPARSE_LPE",
+       "BSMR_SPARSE_ENTRIES_PER_WG", "BSMR_FORCE_TILE32")
 for kn in knobs:
-    for k in ("BSMR_DENSE_CHUNK", "BSMR_SPARSE_LPE", "BSMR_SPARSE_ENTRIES_PER_WG", "BSMR_FORCE_TILE32"):
+    for k in ALL:
         os.environ.pop(k, None)
     os.environ.update(kn)
     st, plan = eng.plan_from_arrays(rows, cols, csr.nnz, arrays, device=0)
