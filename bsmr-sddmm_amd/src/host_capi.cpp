@@ -21,6 +21,7 @@ struct bsmr_csr {
 struct bsmr_pipeline {
     BSMR bsmr;
     std::unique_ptr<RPHM> rphm;
+    int clusters = -1;  // set when the clustering ran outside BSMR (explicit bin width)
 };
 
 namespace {
@@ -94,6 +95,7 @@ bsmr_pipeline* bsmr_pipeline_create(const bsmr_csr* m, float alpha, float delta,
             float t = 0;
             std::vector<UIN> rows = bsa_rowReordering_host(m->m, alpha, block_size, clusters, t);
             if (rows.empty()) return nullptr;
+            p->clusters = clusters;
             p->bsmr.colReordering(delta, m->m, rows);
         } else {
             p->bsmr = BSMR(alpha, delta, m->m, 1);
@@ -141,7 +143,10 @@ int bsmr_pipeline_array(const bsmr_pipeline* p, int which, const uint32_t** data
 }
 
 int bsmr_pipeline_num_row_panels(const bsmr_pipeline* p) { return p ? p->bsmr.numRowPanels() : 0; }
-int bsmr_pipeline_num_clusters(const bsmr_pipeline* p) { return p ? p->bsmr.numClusters() : 0; }
+int bsmr_pipeline_num_clusters(const bsmr_pipeline* p) {
+    if (!p) return 0;
+    return p->clusters >= 0 ? p->clusters : p->bsmr.numClusters();
+}
 float bsmr_pipeline_row_reordering_ms(const bsmr_pipeline* p) { return p ? p->bsmr.rowReorderingTime() : 0; }
 float bsmr_pipeline_col_reordering_ms(const bsmr_pipeline* p) { return p ? p->bsmr.colReorderingTime() : 0; }
 float bsmr_pipeline_rphm_ms(const bsmr_pipeline* p) { return p && p->rphm ? p->rphm->time() : 0; }

@@ -1,0 +1,99 @@
+"""The C-ABI libraries load without a GPU, export every symbol the headers
+declare, and fail with status codes (never crash) when no device is present."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import synth
+
+REPO = Path(__file__).resolve().parent.parent
+INCLUDE = REPO / "include"
+LIB = REPO / "bsmr-sddmm_amd" / "lib"
+
+
+def declared_functions(header: Path):
+    text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(bsmr_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported(lib: Path):
+    out = subprocess.run(["nm", "-D", "--defined-only", str(lib)], check=True, capture_output=True, text=True)
+    return {line.split()[-1] for line in out.stdout.splitlines() if " T " in line}
+
+
+def test_every_declared_symbol_is_exported_and_bound(engine):
+    hip_decl = declared_functions(INCLUDE / "bsmr_hip.h")
+    host_decl = [f for f in declared_functions(INCLUDE / "bsmr_host.h") if f not in hip_decl]
+    assert len(hip_decl) >= 20 and len(host_decl) >= 25
+    hip_exp, host_exp = exported(LIB / "libbsmr_hip.so"), exported(LIB / "libbsmr_host.so")
+    assert not [f for f in hip_decl if f not in hip_exp]
+    assert not [f for f in host_decl if f not in host_exp]
+    # the Python binding covers exactly the declared set (nothing undeclared is used)
+    assert sorted(engine.HIP_SYMBOLS) == hip_decl
+    assert sorted(engine.HOST_SYMBOLS) == host_decl
+
+
+def test_headers_compile_as_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "bsmr_hip.h"\n#include "bsmr_host.h"\nint main(void){return BSMR_OK;}\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(INCLUDE), "-c", str(src), "-o",
+                    str(tmp_path / "t.o")], check=True)
+
+
+def test_strerror_covers_all_codes(engine):
+    hip = engine.hip()
+    texts = [hip.bsmr_strerror(i).decode() for i in range(7)]
+    assert texts[0] == "success" and len(set(texts)) == 7
+    assert hip.bsmr_strerror(99).decode() == "unknown status"
+
+
+def test_argument_validation_without_gpu(engine):
+    hip = engine.hip()
+    assert hip.bsmr_device_count(None) == engine.ERR_INVALID_ARG
+    assert hip.bsmr_plan_create(None, 0, None) == engine.ERR_INVALID_ARG
+    assert hip.bsmr_plan_destroy(None) == engine.OK
+    assert hip.bsmr_plan_get_stats(None, None) == engine.ERR_INVALID_ARG
+    assert hip.bsmr_sddmm(None, 32, None, None, None, 0, None) == engine.ERR_INVALID_ARG
+    assert hip.bsmr_plan_reserve(None, 32) == engine.ERR_INVALID_ARG
+    assert hip.bsmr_dev_free(None) == engine.OK
+    assert hip.bsmr_memcpy_h2d(None, None, 0) == engine.OK
+    assert hip.bsmr_memcpy_h2d(None, None, 8) == engine.ERR_INVALID_ARG
+
+
+def test_no_device_is_an_error_code_not_a_crash(engine):
+    if engine.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the -m gpu tests")
+    rows, cols, ro, ci = synth.random_pattern(20, 20, 100, seed=1)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    pipe = engine.Pipeline(csr, device=-1)
+    st, plan = engine.plan_from_arrays(rows, cols, csr.nnz, pipe.arrays(), device=0)
+    assert st == engine.ERR_NO_DEVICE and not plan.value
+    with pytest.raises(engine.BsmrError):
+        engine.Pipeline(csr, device=0)      # product path fails loudly, no CPU fallback
+    A = np.zeros(rows * 32, np.float32)
+    B = np.zeros(cols * 32, np.float32)
+    with pytest.raises(engine.BsmrError):
+        engine.sddmm_operator(csr, 32, A, B)
+    out = C.c_void_p()
+    assert engine.hip().bsmr_dev_alloc(0, 64, C.byref(out)) == engine.ERR_NO_DEVICE
+
+
+def test_cli_contract(engine, tmp_path):
+    """-f/-k/-a/-d parsing, loader errors and exit codes of bin/BSMR-sddmm (reference src/main.cu)."""
+    exe = REPO / "bsmr-sddmm_amd" / "bin" / "BSMR-sddmm"
+    assert exe.exists()
+    r = subprocess.run([str(exe), "-f", str(tmp_path / "nope.mtx"), "-k", "64"], capture_output=True, text=True)
+    assert r.returncode != 0 and "matrix S initialize failed" in r.stderr
+    rows, cols, ro, ci = synth.random_pattern(40, 50, 300, seed=2)
+    f = tmp_path / "m.mtx"
+    synth.write_mtx(f, rows, cols, ro, ci)
+    r = subprocess.run([str(exe), "-f", str(f), "-k", "32", "-a", "0.5", "-d", "0.1"], capture_output=True,
+                       text=True, timeout=120)
+    # without a GPU the device plan cannot be created, but the record is still printed
+    for key in ("[File : ", "[K : 32]", "[NNZ : 300]", "[bsmr_alpha : 0.5", "[bsmr_delta : 0.1", "[NumRowPanel : ",
+                "[bsmr_numDenseBlock : ", "[bsmr_gflops : "):
+        assert key in r.stdout, (key, r.stdout, r.stderr)
