@@ -106,19 +106,24 @@ def main():
 
     gen, kwargs, K, alpha, delta = WORKLOADS[args.workload]
     mode = {"f16": eng.COMPUTE_F16, "bf16": eng.COMPUTE_BF16, "f32": eng.COMPUTE_F32}[args.mode]
-    rows, cols, ro, ci = getattr(synth, gen)(**kwargs)
-    nnz = int(ci.size)
-
     if world > 1:
         import shard
-        result = shard.run_sharded(eng, torch, dist, dev, rank, world, rows, cols, ro, ci, K, alpha, delta,
-                                   mode, args.steps, args.warmup)
+        # weak scaling: rank r owns row-stacked copy r of the workload pattern (own seed)
+        def make_pattern(r):
+            kw = dict(kwargs)
+            kw["seed"] = {"nips_like": 1, "banded_mesh_like": 2, "bernoulli": 4}[gen] + 100 * r
+            return getattr(synth, gen)(**kw)
+        result = shard.run_sharded(eng, torch, dist, dev, rank, world, make_pattern, K, alpha, delta, mode,
+                                   args.steps, args.warmup, scaling="weak")
         if rank == 0:
-            result.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup})
+            result.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dtype": args.mode})
+            result["config"]["workload"] = f"{args.workload} x{world} (weak): " + result["config"]["workload"]
             print(json.dumps(result))
         dist.destroy_process_group()
         return
 
+    rows, cols, ro, ci = getattr(synth, gen)(**kwargs)
+    nnz = int(ci.size)
     t0 = time.perf_counter()
     csr = eng.CSR.from_arrays(rows, cols, ro, ci)
     pipe = eng.Pipeline(csr, alpha=alpha, delta=delta, device=local_rank)

@@ -1,0 +1,145 @@
+"""Row-range sharding of one SDDMM over the GPUs of a node.
+
+The reference is single-GPU; this layer is new.  Row panels are independent (a
+panel owns a disjoint set of output entries), so:
+
+  * the rows of S are cut into `world` contiguous ranges of (nearly) equal nnz;
+    rank r owns range r: its slice of S (a CSR with local row ids), the matching
+    rows of A, and a full copy of B.  Each rank runs the whole BSMR pipeline
+    (cluster, reorder, split, plan) on its own slice - clustering never crosses a
+    shard boundary - and computes its entries of P in the slice's CSR order.
+  * Because the ranges are contiguous in the original row order, the global P
+    (S's CSR order) is simply the concatenation of the shards' outputs.  The only
+    data-path collective is therefore ONE gather-v to rank 0: every peer sends its
+    compact fp32 vector straight into its slot of the root's P (grouped
+    send/recv = ncclGroupStart/End on RCCL; 7 peers arrive over 7 separate xGMI
+    links).  No permutation pass is needed on the root.
+
+`compute` is injected so that the orchestration can be exercised on CPU (gloo)
+with the oracle standing in for the device; the product path passes the HIP
+launcher.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def partition_rows(row_offsets: np.ndarray, world: int):
+    """Contiguous row ranges with nearly equal nnz: returns world+1 row boundaries."""
+    ro = row_offsets.astype(np.int64)
+    rows = ro.size - 1
+    nnz = int(ro[-1])
+    bounds = [0]
+    for r in range(1, world):
+        target = nnz * r // world
+        cut = int(np.searchsorted(ro, target, side="left"))
+        cut = min(max(cut, bounds[-1]), rows)
+        bounds.append(cut)
+    bounds.append(rows)
+    return bounds
+
+
+def local_slice(rows, cols, ro, ci, r0, r1):
+    """CSR of rows [r0, r1) with local row ids; also the slice's offset in the global P."""
+    ro64 = ro.astype(np.int64)
+    e0, e1 = int(ro64[r0]), int(ro64[r1])
+    lro = (ro64[r0:r1 + 1] - e0).astype(np.uint32)
+    return r1 - r0, cols, lro, ci[e0:e1].copy(), e0, e1 - e0
+
+
+def gather_to_root(dist, rank, world, local_out, root_out, offsets, counts):
+    """One gather-v: peers send their compact outputs into root_out[offsets[r]:+counts[r]].
+    On the root the local result already lives in its own slot of root_out."""
+    if world == 1:
+        return
+    ops = []
+    if rank == 0:
+        for r in range(1, world):
+            if counts[r]:
+                ops.append(dist.P2POp(dist.irecv, root_out[offsets[r]:offsets[r] + counts[r]], r))
+    elif counts[rank]:
+        ops.append(dist.P2POp(dist.isend, local_out, 0))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+def sharded_sddmm(dist, rank, world, ro, counts_offsets, compute, local_out, root_out):
+    """compute() fills local_out (the root's local_out is a view into root_out); then gather."""
+    offsets, counts = counts_offsets
+    compute()
+    gather_to_root(dist, rank, world, local_out, root_out, offsets, counts)
+
+
+def run_sharded(eng, torch, dist, dev, rank, world, make_pattern, K, alpha, delta, mode, steps, warmup,
+                scaling="weak"):
+    """bench.py's N > 1 path.  weak scaling: the job is `world` row-stacked patterns
+    (rank r generates and owns copy r); strong: one pattern cut into `world` ranges."""
+    import time
+
+    if scaling == "weak":
+        rows, cols, lro, lci = make_pattern(rank)
+        counts = [0] * world
+        t = torch.tensor([lci.size], dtype=torch.int64, device=dev)
+        allc = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(allc, t)
+        counts = [int(c.item()) for c in allc]
+        lrows, lnnz = rows, int(lci.size)
+        total_rows = rows * world
+    else:
+        rows, cols, ro, ci = make_pattern(0)
+        b = partition_rows(ro, world)
+        parts = [local_slice(rows, cols, ro, ci, b[r], b[r + 1]) for r in range(world)]
+        lrows, _, lro, lci, _, lnnz = parts[rank]
+        counts = [p[5] for p in parts]
+        total_rows = rows
+    offsets = [0]
+    for c in counts[:-1]:
+        offsets.append(offsets[-1] + c)
+    total_nnz = sum(counts)
+
+    t0 = time.perf_counter()
+    csr = eng.CSR.from_arrays(lrows, cols, lro, lci)
+    pipe = eng.Pipeline(csr, alpha=alpha, delta=delta, device=dev.index)
+    plan_s = time.perf_counter() - t0
+    A = torch.from_numpy(eng.make_data(lrows * K, 5489 + 17 * rank)).to(dev)
+    B = torch.from_numpy(eng.make_data(cols * K, 5490)).to(dev)   # replicated
+    root_out = torch.zeros(total_nnz if rank == 0 else 1, dtype=torch.float32, device=dev)
+    local_out = root_out[:lnnz] if rank == 0 else torch.zeros(max(lnnz, 1), dtype=torch.float32, device=dev)[:lnnz]
+    sh = torch.cuda.current_stream(dev).cuda_stream
+    eng.hip().bsmr_plan_reserve(pipe.plan, K)
+
+    def compute():
+        eng.sddmm(pipe.plan, K, A.data_ptr(), B.data_ptr(), local_out.data_ptr(), mode, sh)
+
+    def step():
+        compute()
+        gather_to_root(dist, rank, world, local_out, root_out, offsets, counts)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ms = float(dt.item()) / steps * 1e3
+
+    # compute-only time (no gather), max over ranks
+    kt = eng.sddmm_timed(pipe.plan, K, A.data_ptr(), B.data_ptr(), local_out.data_ptr(), mode, sh, 3, max(steps // 4, 5))
+    ct = torch.tensor([kt["total_ms"]], dtype=torch.float64, device=dev)
+    dist.all_reduce(ct, op=dist.ReduceOp.MAX)
+    return {
+        "metric": "SDDMM GFLOP/s", "value": round(2.0 * total_nnz * K / (ms * 1e6), 2), "unit": "GFLOP/s",
+        "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "data": "synthetic",
+        "config": {"workload": f"{world} row shards of {lrows} rows x {cols} cols, total {total_rows} rows, "
+                               f"nnz {total_nnz}, K={K}, alpha={alpha}, delta={delta}",
+                   "parallelism": f"row-range shards x{world}, B replicated, one RCCL gather-v to rank 0 per step"},
+        "compute_only_ms_max": round(float(ct.item()), 5),
+        "plan_build_s": round(plan_s, 3),
+    }

@@ -1,0 +1,82 @@
+"""Worker for tests/test_shard_gloo.py: 2+ CPU ranks over gloo run the sharded
+orchestration of bsmr-sddmm_amd/python/shard.py with the oracle standing in for the
+device kernels, and the root checks the gathered P against a single-process oracle."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "bsmr-sddmm_amd" / "python"))
+sys.path.insert(0, str(REPO / "tests"))
+import bsmr_amd as eng  # noqa: E402
+import shard  # noqa: E402
+import synth  # noqa: E402
+from conftest import Oracle  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    oracle = Oracle()
+    K = 64
+    rows, cols, ro, ci = synth.random_pattern(97, 120, 2500, seed=5, empty_rows=6)
+    A = eng.make_data(rows * K, 21)
+    B = eng.make_data(cols * K, 22)
+
+    # ---- strong: one pattern cut into contiguous row ranges of equal nnz ----
+    bounds = shard.partition_rows(ro, world)
+    assert bounds[0] == 0 and bounds[-1] == rows and all(a <= b for a, b in zip(bounds, bounds[1:]))
+    parts = [shard.local_slice(rows, cols, ro, ci, bounds[r], bounds[r + 1]) for r in range(world)]
+    counts = [p[5] for p in parts]
+    offsets = [p[4] for p in parts]
+    assert sum(counts) == ci.size and offsets == list(np.cumsum([0] + counts[:-1]))
+    lrows, _, lro, lci, e0, lnnz = parts[rank]
+    # every rank runs the whole host pipeline on its slice (device=-1: no GPU here)
+    csr = eng.CSR.from_arrays(lrows, cols, lro, lci)
+    pipe = eng.Pipeline(csr, alpha=0.3, delta=0.2, device=-1)
+    assert pipe.check()
+    root_out = torch.zeros(ci.size if rank == 0 else 1, dtype=torch.float32)
+    local_out = root_out[:lnnz] if rank == 0 else torch.zeros(lnnz, dtype=torch.float32)
+    A_local = A.reshape(rows, K)[bounds[rank]:bounds[rank + 1]].ravel().copy()
+
+    def compute():  # the oracle plays the device: local slice, local rows of A, all of B
+        local_out.copy_(torch.from_numpy(oracle.sddmm_cpu(lrows, cols, K, lro, lci, A_local, B)))
+
+    shard.sharded_sddmm(dist, rank, world, ro, (offsets, counts), compute, local_out, root_out)
+    if rank == 0:
+        want = oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B)
+        assert np.array_equal(root_out.numpy().view(np.uint32), want.view(np.uint32)), "strong: gathered P differs"
+
+    # ---- weak: rank r owns row-stacked copy r (its own pattern and A rows) ----
+    prow, pcol, pro, pci = synth.random_pattern(40, cols, 600 + 50 * rank, seed=100 + rank)
+    n = torch.tensor([pci.size], dtype=torch.int64)
+    allc = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allc, n)
+    counts = [int(c.item()) for c in allc]
+    offsets = [int(x) for x in np.cumsum([0] + counts[:-1])]
+    Ar = eng.make_data(prow * K, 300 + rank)
+    root_out = torch.zeros(sum(counts) if rank == 0 else 1, dtype=torch.float32)
+    local_out = root_out[:counts[0]] if rank == 0 else torch.zeros(counts[rank], dtype=torch.float32)
+
+    def compute_weak():
+        local_out.copy_(torch.from_numpy(oracle.sddmm_cpu(prow, pcol, K, pro, pci, Ar, B)))
+
+    shard.sharded_sddmm(dist, rank, world, None, (offsets, counts), compute_weak, local_out, root_out)
+    if rank == 0:
+        got = root_out.numpy()
+        for r in range(world):
+            rr, rc, rro, rci = synth.random_pattern(40, cols, 600 + 50 * r, seed=100 + r)
+            want = oracle.sddmm_cpu(rr, rc, K, rro, rci, eng.make_data(rr * K, 300 + r), B)
+            seg = got[offsets[r]:offsets[r] + counts[r]]
+            assert np.array_equal(seg.view(np.uint32), want.view(np.uint32)), f"weak: shard {r} differs"
+        print("SHARD_OK", world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into committed evidence:
+  profiles/<round>_<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary
+  profiles/<round>_<tag>_pmc.json           per-kernel mean counter values
+  profiles/traffic.json                     HBM bytes per launch of the dominant kernel
+usage: tools/summarize_prof.py <round> <tag> <workload> <mode>"""
+import collections
+import csv
+import glob
+import json
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+rnd, tag, workload, mode = sys.argv[1:5]
+src = REPO / "gpurun_out" / f"prof_{tag}"
+dst = REPO / "profiles"
+stats = glob.glob(str(src / "stats" / "**" / "*kernel_stats.csv"), recursive=True)[0]
+(dst / f"{rnd}_{tag}_kernel_stats.csv").write_text(Path(stats).read_text())
+pmc = collections.defaultdict(dict)
+for f in glob.glob(str(src / "pmc_*" / "**" / "*counter_collection.csv"), recursive=True):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "bsmr::" in r["Kernel_Name"]:
+            agg[(r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in agg.items():
+        pmc[k][c] = {"launches": len(v), "mean": sum(v) / len(v)}
+bench = json.loads((src / "bench.json").read_text().strip().splitlines()[-1])
+(dst / f"{rnd}_{tag}_bench.json").write_text(json.dumps(bench, indent=1))
+out = {"bench": {k: bench[k] for k in ("value", "ms_per_step", "kernels_ms", "roofline")}, "pmc": pmc}
+# HBM traffic of the dominant kernel, per launch: FETCH_SIZE / WRITE_SIZE are in KiB; gfx950
+# FETCH_SIZE counts half of a 16-B-per-lane stream (MI355X_MICROARCH.md "HBM"), so it is doubled.
+dom = bench["roofline"]["kernel"]
+name = {"dense": "denseGroups", "sparse": "sparseEntries", "convert": "convertOperands"}[dom]
+for k, c in pmc.items():
+    if name in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        traffic = int((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
+        out["traffic_bytes_per_launch"] = traffic
+        tfile = dst / "traffic.json"
+        t = json.loads(tfile.read_text()) if tfile.exists() else {}
+        t[f"{workload}:{mode}:{dom}"] = traffic
+        tfile.write_text(json.dumps(t, indent=1))
+(dst / f"{rnd}_{tag}_pmc.json").write_text(json.dumps(out, indent=1))
+print(open(dst / f"{rnd}_{tag}_kernel_stats.csv").read()[:1500])
+print(json.dumps(out, indent=1)[:3000])
