@@ -40,7 +40,18 @@ WORKLOADS = {
     "nips_k32_hybrid": ("nips_like", {}, 32, 0.3, 0.3),       # configs[0] on the GPU
     "nips_k512_dense": ("nips_like", {}, 512, 0.3, 0.0),
     "cop20k_k128_hybrid": ("banded_mesh_like", {}, 128, 0.3, 0.3),  # configs[2]
-    "dlmc_k512_dense": ("bernoulli", {}, 512, 0.3, 0.0),      # configs[4] (delta = 0 point)
+    "dlmc_k512_dense": ("bernoulli", {}, 512, 0.3, 0.0),      # configs[4], delta = 0 point of the sweep
+    "dlmc_k512_d01": ("bernoulli", {}, 512, 0.3, 0.1),
+    "dlmc_k512_sparse": ("bernoulli", {}, 512, 0.3, 1.1),     # configs[4], delta = 1.1 point
+}
+BASELINE_CONFIG = {
+    "nips_k128_dense": "BASELINE configs[1] stand-in; real nips.mtx unavailable offline",
+    "nips_k32_hybrid": "BASELINE configs[0] shape run on the GPU",
+    "nips_k512_dense": "K=512 point of the metric",
+    "cop20k_k128_hybrid": "BASELINE configs[2] stand-in; real cop20k_A.mtx unavailable offline",
+    "dlmc_k512_dense": "BASELINE configs[4] stand-in (4096^2, 90 % sparse), delta=0",
+    "dlmc_k512_d01": "BASELINE configs[4] stand-in, delta=0.1",
+    "dlmc_k512_sparse": "BASELINE configs[4] stand-in, delta=1.1 (sparse path only)",
 }
 
 
@@ -177,7 +188,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mode,
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {gen} {rows}x{cols} nnz={nnz} K={K} alpha={alpha} "
-                               f"delta={delta} (BASELINE configs[1] stand-in; real nips.mtx unavailable)",
+                               f"delta={delta} ({BASELINE_CONFIG[args.workload]})",
                    "boundary": "fp32 A,B in HBM -> fp32 P in HBM via bsmr_sddmm (conversion included)",
                    "dense_blocks": stats["num_dense_blocks"], "dense_tiles": stats["num_dense_tiles"], "group_size": stats["group_size"], "union_columns": stats["union_columns"], "dense_nnz": stats["num_dense_entries"],
                    "sparse_nnz": stats["num_sparse_entries"]},

@@ -52,6 +52,7 @@ struct bsmr_plan {
     uint32_t reservedK = 0;
 
     int sparseLpe = 8;
+    bool convertInKernel = false;  // dense part so small that the full operand conversion pass does not pay
     int denseBatch = 0;  // blocks per LDS batch for K <= 128 (0 = default)
 };
 
@@ -184,6 +185,22 @@ int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uin
     return BSMR_OK;
 }
 
+template <int MODE>
+int launchDenseCvt(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, hipStream_t s) {
+    if (p->numDenseItems == 0) return BSMR_OK;
+    const uint32_t wgs = (p->numDenseItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
+    if (p->tiles16)
+        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint16_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           p->H, p->groupRows, p->groupRowBase, p->blockCols, p->tiles16, p->blockMask,
+                           p->denseItems, p->numDenseItems, P);
+    else
+        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint32_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           p->H, p->groupRows, p->groupRowBase, p->blockCols, p->tiles32, p->blockMask,
+                           p->denseItems, p->numDenseItems, P);
+    BSMR_HIP(hipGetLastError());
+    return BSMR_OK;
+}
+
 int launchDense32(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P,
                   hipStream_t s) {
     if (p->numDenseItems == 0) return BSMR_OK;
@@ -256,6 +273,11 @@ int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P
     int st = BSMR_OK;
     if (mode == BSMR_COMPUTE_F32) {
         if ((which & 2) && (st = launchDense32(p, K, A, B, P, s)) != BSMR_OK) return st;
+    } else if (p->convertInKernel) {
+        if (which & 2) {
+            st = mode == BSMR_COMPUTE_F16 ? launchDenseCvt<0>(p, K, A, B, P, s) : launchDenseCvt<1>(p, K, A, B, P, s);
+            if (st != BSMR_OK) return st;
+        }
     } else {
         if (p->numDenseItems) {
             if (which & 1) {
@@ -413,6 +435,11 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         p->sparseLpe = envInt("BSMR_SPARSE_LPE", 8);
         if (p->sparseLpe != 4 && p->sparseLpe != 8 && p->sparseLpe != 16) p->sparseLpe = 8;
         p->denseBatch = envInt("BSMR_DENSE_BATCH", 0);
+        // full conversion moves 6 bytes per operand element; the in-kernel path reads each
+        // gathered element as fp32 (4 B, A re-read per block) from a slower kernel
+        const int cvt = envInt("BSMR_CONVERT_IN_KERNEL", -1);
+        p->convertInKernel = cvt >= 0 ? cvt != 0
+                                      : pk.unionColumns * 16ull < ((uint64_t)d->M + d->N) * 6ull;
 
         st = upload(p->panelRows, pk.panelRows, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->groupRows, pk.groupRows, p->indexBytes);
@@ -475,7 +502,9 @@ int bsmr_sddmm(bsmr_plan* plan, uint32_t K, const float* A, const float* B, floa
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     BSMR_HIP(hipSetDevice(plan->device));
-    if (mode != BSMR_COMPUTE_F32 && plan->numDenseItems && (st = reserve(plan, K)) != BSMR_OK) return st;
+    if (mode != BSMR_COMPUTE_F32 && plan->numDenseItems && !plan->convertInKernel &&
+        (st = reserve(plan, K)) != BSMR_OK)
+        return st;
     return runPieces(plan, K, A, B, P, mode, static_cast<hipStream_t>(stream), 7);
 }
 
@@ -514,7 +543,9 @@ int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     if (st != BSMR_OK) return st;
     if (!out || iters <= 0 || warmup < 0) return BSMR_ERR_INVALID_ARG;
     BSMR_HIP(hipSetDevice(plan->device));
-    if (mode != BSMR_COMPUTE_F32 && plan->numDenseItems && (st = reserve(plan, K)) != BSMR_OK) return st;
+    if (mode != BSMR_COMPUTE_F32 && plan->numDenseItems && !plan->convertInKernel &&
+        (st = reserve(plan, K)) != BSMR_OK)
+        return st;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BSMR_HIP(hipEventCreate(&e0));
@@ -537,7 +568,8 @@ int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     for (int i = 0; i < warmup && st == BSMR_OK; ++i) st = runPieces(plan, K, A, B, P, mode, s, 7);
     bsmr_timing t{};
     if (st == BSMR_OK) st = timeLoop(7, t.total_ms);
-    if (st == BSMR_OK && mode != BSMR_COMPUTE_F32 && plan->numDenseItems) st = timeLoop(1, t.convert_ms);
+    if (st == BSMR_OK && mode != BSMR_COMPUTE_F32 && plan->numDenseItems && !plan->convertInKernel)
+        st = timeLoop(1, t.convert_ms);
     if (st == BSMR_OK && plan->numDenseItems) st = timeLoop(2, t.dense_ms);
     if (st == BSMR_OK && plan->numSparseItems) st = timeLoop(4, t.sparse_ms);
     (void)hipEventDestroy(e0);

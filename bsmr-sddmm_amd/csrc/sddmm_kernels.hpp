@@ -333,6 +333,63 @@ denseGroupsAnyK(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B
 }
 
 // ---------------------------------------------------------------------------
+// dense kernel for a SMALL dense part: fp32 operands converted to fp16 / bf16 in
+// registers (round-to-nearest-even, the same values the convertOperands pass
+// would produce), so the full-matrix conversion pass can be skipped when only a
+// few blocks are dense.  One wave per DenseItem, fragments from global memory.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ u32x4 packLowp(const f32x4& lo, const f32x4& hi) {
+    if constexpr (MODE == 0) {
+        f16x8 o;
+        o[0] = (_Float16)lo[0]; o[1] = (_Float16)lo[1]; o[2] = (_Float16)lo[2]; o[3] = (_Float16)lo[3];
+        o[4] = (_Float16)hi[0]; o[5] = (_Float16)hi[1]; o[6] = (_Float16)hi[2]; o[7] = (_Float16)hi[3];
+        return __builtin_bit_cast(u32x4, o);
+    } else {
+        bf16x8 o;
+        o[0] = (__bf16)lo[0]; o[1] = (__bf16)lo[1]; o[2] = (__bf16)lo[2]; o[3] = (__bf16)lo[3];
+        o[4] = (__bf16)hi[0]; o[5] = (__bf16)hi[1]; o[6] = (__bf16)hi[2]; o[7] = (__bf16)hi[3];
+        return __builtin_bit_cast(u32x4, o);
+    }
+}
+
+template <int MODE, typename TileT>
+__global__ void __launch_bounds__(kThreads)
+denseGroupsCvt(const float* __restrict__ A, const float* __restrict__ B, uint32_t K, uint32_t H,
+               const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ groupRowBase,
+               const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
+               const uint8_t* __restrict__ blockMask, const DenseItem* __restrict__ items,
+               uint32_t numItems, float* __restrict__ P) {
+    const uint32_t itemId = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
+    if (itemId >= numItems) return;
+    const DenseItem item = items[itemId];
+    const uint32_t lane = threadIdx.x & 63u, r = lane & 15u, g = lane >> 4;
+    const uint32_t steps = K >> 5;
+    for (uint32_t b = item.first; b < item.first + item.count; ++b) {
+        const uint32_t mask = blockMask[b];
+        const float* bCol = B + (size_t)blockCols[(size_t)b * 16u + r] * K + g * 8u;
+        for (uint32_t h = 0; h < H; ++h) {
+            if (!(mask & (1u << h))) continue;
+            const uint32_t slot = item.group * 16u * H + h * 16u;
+            const float* aRow = A + (size_t)groupRows[slot + r] * K + g * 8u;
+            const typename TileLoad<TileT>::raw tile = loadTile<TileT>(tiles, (size_t)b * H + h, lane);
+            uint32_t rowBase[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rowBase[i] = groupRowBase[slot + 4u * g + i];
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (uint32_t s = 0; s < steps; ++s) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(aRow + s * 32u);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(aRow + s * 32u + 4u);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bCol + s * 32u);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bCol + s * 32u + 4u);
+                acc = mfma16<MODE>(packLowp<MODE>(a0, a1), packLowp<MODE>(b0, b1), acc);
+            }
+            scatterTile<TileT>(acc, tile, rowBase, P);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // dense kernel, exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain.
 // Lane (r, g) loads float4 chunks [16t + 4g, +4) of its row / column; MFMA
 // number (t, j) multiplies element j of every chunk, so inside it lane group g

@@ -107,6 +107,40 @@ def test_large_k_sparse_without_lds(engine, oracle):
     check_case(engine, oracle, rows, cols, ro, ci, 2048, 0.3, 1.1, 0)
 
 
+@pytest.mark.parametrize("knobs", [
+    {"BSMR_DENSE_GROUP": "2"}, {"BSMR_DENSE_GROUP": "4"},
+    {"BSMR_DENSE_GROUP": "4", "BSMR_DENSE_BLOCKS_PER_WG": "3"},
+    {"BSMR_DENSE_GROUP": "2", "BSMR_DENSE_BATCH": "8", "BSMR_DENSE_BLOCKS_PER_WG": "64"},
+    {"BSMR_CONVERT_IN_KERNEL": "1"}, {"BSMR_CONVERT_IN_KERNEL": "0"},
+    {"BSMR_CONVERT_IN_KERNEL": "1", "BSMR_DENSE_GROUP": "4"},
+    {"BSMR_FORCE_TILE32": "1", "BSMR_DENSE_GROUP": "2"},
+    {"BSMR_SPARSE_LPE": "4", "BSMR_SPARSE_ENTRIES_PER_WG": "32"}, {"BSMR_SPARSE_LPE": "16"},
+])
+@pytest.mark.parametrize("K", [32, 128, 512])
+def test_plan_knobs(engine, oracle, monkeypatch, knobs, K):
+    """Every plan-time variant (panel grouping, batch sizes, in-kernel conversion, wide tiles,
+    sparse lane split) computes the same entries."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    rows, cols, ro, ci = synth.community_graph(n=330, avg_degree=40, communities=6, seed=K)
+    lpe = int(knobs.get("BSMR_SPARSE_LPE", 8))
+    for delta in (0.0, 0.1):
+        for mode in (0, 1):
+            csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+            pipe = engine.Pipeline(csr, alpha=0.2, delta=delta, device=0)
+            A = engine.make_data(rows * K, 5489)
+            B = engine.make_data(cols * K, 5490)
+            got = run_hip(engine, pipe, K, A, B, mode)
+            twin, flags, model = expected_twin(oracle, pipe, K, ro, ci, A, B, mode, lpe=lpe)
+            s = ~flags
+            assert np.array_equal(got[s].view(np.uint32), twin[s].view(np.uint32))
+            absdot = oracle.sddmm_f64(rows, K, ro, ci, np.abs(A), np.abs(B))
+            err = np.abs(got[flags].astype(np.float64) - model[flags])
+            assert (err <= (K / 32 + 4) * 2.0 ** -23 * absdot[flags]).all()
+            if "BSMR_DENSE_GROUP" in knobs:
+                assert pipe.plan_stats()["group_size"] == int(knobs["BSMR_DENSE_GROUP"])
+
+
 def test_output_indexing_is_exact(engine, oracle):
     """A = one-hot rows, B = column id: every entry's exact value identifies (row, col)."""
     rows, cols, ro, ci = synth.random_pattern(130, 500, 4000, seed=21, empty_rows=4)
