@@ -176,7 +176,8 @@ def main():
         alg_bytes = (rows + cols) * K * (4 + 2)
     dom_ms = kt[f"{dominant}_ms"]
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-    exec_flops = stats["num_dense_tiles"] * 2 * 256 * K
+    choice = pipe.dense_choice(K)
+    exec_flops = choice["tiles"] * 2 * 256 * K
     traffic = None
     tfile = REPO / "profiles" / "traffic.json"
     if tfile.exists():
@@ -190,7 +191,7 @@ def main():
         "config": {"workload": f"{args.workload}: {gen} {rows}x{cols} nnz={nnz} K={K} alpha={alpha} "
                                f"delta={delta} ({BASELINE_CONFIG[args.workload]})",
                    "boundary": "fp32 A,B in HBM -> fp32 P in HBM via bsmr_sddmm (conversion included)",
-                   "dense_blocks": stats["num_dense_blocks"], "dense_tiles": stats["num_dense_tiles"], "group_size": stats["group_size"], "union_columns": stats["union_columns"], "dense_nnz": stats["num_dense_entries"],
+                   "dense_blocks": stats["num_dense_blocks"], "dense_tiles": choice["tiles"], "group_size": choice["group_size"], "union_columns": choice["union_columns"], "dense_nnz": stats["num_dense_entries"],
                    "sparse_nnz": stats["num_sparse_entries"]},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

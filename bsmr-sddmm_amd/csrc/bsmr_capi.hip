@@ -1,6 +1,7 @@
 // C ABI of libbsmr_hip.so (include/bsmr_hip.h): device management, plan
-// construction (RPHM host arrays -> compact device format), kernel launchers and
-// event timing.  See the header for the reference interfaces each entry replaces.
+// construction (RPHM host arrays -> device format, csrc/plan_pack.hpp), kernel
+// launchers and event timing.  See the header for the reference interfaces each
+// entry replaces.
 
 #include "bsmr_hip.h"
 
@@ -23,27 +24,40 @@ using bsmr::SparseItem;
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
-struct bsmr_plan {
-    int device = 0;
-    uint32_t M = 0, N = 0, nnz = 0, numPanels = 0;
-    uint32_t H = 1;  // row panels per group of the dense path
-
-    // device-resident metadata (host layout: csrc/plan_pack.hpp)
-    uint32_t* panelRows = nullptr;
+// Device-resident dense part for one group size H (host layout: csrc/plan_pack.hpp).
+struct DenseFormat {
+    uint32_t H = 0;  // 0 = absent
     uint32_t* groupRows = nullptr;
     uint32_t* groupRowBase = nullptr;
     uint32_t* blockCols = nullptr;
     uint16_t* tiles16 = nullptr;
     uint32_t* tiles32 = nullptr;
     uint8_t* blockMask = nullptr;
-    DenseItem* denseItems = nullptr;
+    DenseItem* items = nullptr;
+    uint32_t numItems = 0;
+    uint64_t numBlocks = 0, numTiles = 0, unionColumns = 0;
+};
+
+struct bsmr_plan {
+    int device = 0;
+    uint32_t M = 0, N = 0, nnz = 0, numPanels = 0;
+
+    // Dense part.  fmt[0] is always present when the matrix has dense blocks;
+    // fmt[1] (4 panels per group) is built in addition when grouping removes at
+    // least a quarter of the B column gathers, and is used for calls whose
+    // ungrouped gather would exceed kGroupedGatherBytes.
+    DenseFormat fmt[2];
+    uint64_t numDenseEntries = 0;
+
+    // sparse residue
+    uint32_t* panelRows = nullptr;
     uint32_t* entryCol = nullptr;
     uint32_t* entryDst = nullptr;
     uint8_t* entryRow = nullptr;
     SparseItem* sparseItems = nullptr;
+    uint64_t numSparseEntries = 0;
+    uint32_t numSparseItems = 0;
 
-    uint64_t numBlocks = 0, numTiles = 0, unionColumns = 0, numDenseEntries = 0, numSparseEntries = 0;
-    uint32_t numDenseItems = 0, numSparseItems = 0;
     uint64_t indexBytes = 0;
 
     // operand workspace (16-bit copies of A and B), grown on demand
@@ -53,10 +67,15 @@ struct bsmr_plan {
 
     int sparseLpe = 8;
     bool convertInKernel = false;  // dense part so small that the full operand conversion pass does not pay
-    int denseBatch = 0;  // blocks per LDS batch for K <= 128 (0 = default)
+    int denseBatch = 0;            // blocks per LDS batch at K = 128 (0 = default)
 };
 
 namespace {
+
+// Measured on MI355X (profiles/r01_dense_ablation.md): grouping 4 panels loses at
+// 88 MB of ungrouped B gather (nips-like K=128: 14.2 vs 18.9 us) and wins at 353 MB
+// (nips-like K=512: 58.9 vs 45.1 us) and 876 MB (4096^2 10 % K=512: 103 vs 39.8 us).
+constexpr uint64_t kGroupedGatherBytes = 200ull << 20;
 
 thread_local std::string g_lastHipError;
 
@@ -102,14 +121,38 @@ int envInt(const char* name, int fallback) {
 }
 
 void freePlanDevice(bsmr_plan* p) {
-    void* ptrs[] = {p->panelRows, p->groupRows, p->groupRowBase, p->blockCols, p->tiles16, p->tiles32,
-                    p->blockMask, p->denseItems, p->entryCol, p->entryDst, p->entryRow, p->sparseItems,
-                    p->A16, p->B16};
+    for (DenseFormat& f : p->fmt) {
+        void* ptrs[] = {f.groupRows, f.groupRowBase, f.blockCols, f.tiles16, f.tiles32, f.blockMask, f.items};
+        for (void* q : ptrs)
+            if (q) (void)hipFree(q);
+        f = DenseFormat{};
+    }
+    void* ptrs[] = {p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, p->A16, p->B16};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
 }
 
-inline uint32_t gridFor(uint32_t workgroups) { return (workgroups + 7u) & ~7u; }  // multiple of 8 XCDs
+int uploadDense(DenseFormat& f, const bsmr::PackedPlan& pk, uint64_t& bytes) {
+    f.H = pk.H;
+    f.numItems = (uint32_t)pk.denseItems.size();
+    f.numBlocks = pk.numBlocks;
+    f.numTiles = pk.numTiles;
+    f.unionColumns = pk.unionColumns;
+    int st = upload(f.groupRows, pk.groupRows, bytes);
+    if (st == BSMR_OK) st = upload(f.groupRowBase, pk.groupRowBase, bytes);
+    if (st == BSMR_OK) st = upload(f.blockCols, pk.blockCols, bytes);
+    if (st == BSMR_OK) st = upload(f.tiles16, pk.tiles16, bytes);
+    if (st == BSMR_OK) st = upload(f.tiles32, pk.tiles32, bytes);
+    if (st == BSMR_OK) st = upload(f.blockMask, pk.blockMask, bytes);
+    if (st == BSMR_OK) st = upload(f.items, pk.denseItems, bytes);
+    return st;
+}
+
+// Dense format for a call with inner dimension K.
+const DenseFormat& chooseFormat(const bsmr_plan* p, uint32_t K) {
+    if (p->fmt[1].H && p->fmt[0].unionColumns * (uint64_t)K * 2ull >= kGroupedGatherBytes) return p->fmt[1];
+    return p->fmt[0];
+}
 
 // --- launchers -------------------------------------------------------------
 template <int MODE>
@@ -128,91 +171,95 @@ int launchConvert(const bsmr_plan* p, uint32_t K, const float* A, const float* B
 // LDS-staged dense kernel for K = 32*KS: KS, H (panels per group) and NB (blocks
 // per workgroup batch) are compile-time.  LDS = 2 * NB * KS KiB.
 template <int KS, int H, int NB, int MODE, typename TileT>
-int launchGroupsT(const bsmr_plan* p, const uint16_t* A16, const uint16_t* B16, const TileT* tiles, float* P,
+int launchGroupsT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, const TileT* tiles, float* P,
                   hipStream_t s) {
     auto kernel = bsmr::denseGroups<KS, H, NB, MODE, TileT>;
     const size_t lds = (size_t)2 * NB * 1024u * KS;  // double-buffered batch of NB blocks
-    static bool raised = false;  // per instantiation
+    static bool raised = false;                      // per instantiation
     if (lds > 64 * 1024 && !raised) {
         BSMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         raised = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(p->numDenseItems), dim3(bsmr::kThreads), lds, s, A16, B16, p->groupRows,
-                       p->groupRowBase, p->blockCols, tiles, p->blockMask, p->denseItems, P);
+    hipLaunchKernelGGL(kernel, dim3(f.numItems), dim3(bsmr::kThreads), lds, s, A16, B16, f.groupRows,
+                       f.groupRowBase, f.blockCols, tiles, f.blockMask, f.items, P);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
 
 template <int KS, int H, int NB, int MODE>
-int launchGroups(const bsmr_plan* p, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
-    return p->tiles16 ? launchGroupsT<KS, H, NB, MODE, uint16_t>(p, A16, B16, p->tiles16, P, s)
-                      : launchGroupsT<KS, H, NB, MODE, uint32_t>(p, A16, B16, p->tiles32, P, s);
+int launchGroups(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+    return f.tiles16 ? launchGroupsT<KS, H, NB, MODE, uint16_t>(f, A16, B16, f.tiles16, P, s)
+                     : launchGroupsT<KS, H, NB, MODE, uint32_t>(f, A16, B16, f.tiles32, P, s);
 }
 
 template <int KS, int NB, int MODE>
-int launchGroupsH(const bsmr_plan* p, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
-    switch (p->H) {
-    case 1: return launchGroups<KS, 1, NB, MODE>(p, A16, B16, P, s);
-    case 2: return launchGroups<KS, 2, NB, MODE>(p, A16, B16, P, s);
-    default: return launchGroups<KS, 4, NB, MODE>(p, A16, B16, P, s);
+int launchGroupsH(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+    switch (f.H) {
+    case 1: return launchGroups<KS, 1, NB, MODE>(f, A16, B16, P, s);
+    case 2: return launchGroups<KS, 2, NB, MODE>(f, A16, B16, P, s);
+    default: return launchGroups<KS, 4, NB, MODE>(f, A16, B16, P, s);
     }
 }
 
 template <int MODE>
 int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
                   hipStream_t s) {
-    if (p->numDenseItems == 0) return BSMR_OK;
+    const DenseFormat& f = chooseFormat(p, K);
+    if (f.numItems == 0) return BSMR_OK;
     switch (K) {
-    case 32: return launchGroupsH<1, 16, MODE>(p, A16, B16, P, s);
-    case 64: return launchGroupsH<2, 8, MODE>(p, A16, B16, P, s);
-    case 128: return p->denseBatch == 8 ? launchGroupsH<4, 8, MODE>(p, A16, B16, P, s)
-                                        : launchGroupsH<4, 4, MODE>(p, A16, B16, P, s);
-    case 256: return launchGroupsH<8, 4, MODE>(p, A16, B16, P, s);
-    case 512: return launchGroupsH<16, 2, MODE>(p, A16, B16, P, s);
+    case 32: return launchGroupsH<1, 16, MODE>(f, A16, B16, P, s);
+    case 64: return launchGroupsH<2, 8, MODE>(f, A16, B16, P, s);
+    case 128: return p->denseBatch == 8 ? launchGroupsH<4, 8, MODE>(f, A16, B16, P, s)
+                                        : launchGroupsH<4, 4, MODE>(f, A16, B16, P, s);
+    case 256: return launchGroupsH<8, 4, MODE>(f, A16, B16, P, s);
+    case 512: return launchGroupsH<16, 2, MODE>(f, A16, B16, P, s);
     default: break;
     }
-    const uint32_t wgs = (p->numDenseItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
-    if (p->tiles16)
+    const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
+    if (f.tiles16)
         hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint16_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A16,
-                           B16, K, p->H, p->groupRows, p->groupRowBase, p->blockCols, p->tiles16, p->blockMask,
-                           p->denseItems, p->numDenseItems, P);
+                           B16, K, f.H, f.groupRows, f.groupRowBase, f.blockCols, f.tiles16, f.blockMask,
+                           f.items, f.numItems, P);
     else
         hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint32_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A16,
-                           B16, K, p->H, p->groupRows, p->groupRowBase, p->blockCols, p->tiles32, p->blockMask,
-                           p->denseItems, p->numDenseItems, P);
+                           B16, K, f.H, f.groupRows, f.groupRowBase, f.blockCols, f.tiles32, f.blockMask,
+                           f.items, f.numItems, P);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
 
+// fp32 operands, rounded to fp16 / bf16 in registers (small dense parts)
 template <int MODE>
 int launchDenseCvt(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, hipStream_t s) {
-    if (p->numDenseItems == 0) return BSMR_OK;
-    const uint32_t wgs = (p->numDenseItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
-    if (p->tiles16)
+    const DenseFormat& f = p->fmt[0];
+    if (f.numItems == 0) return BSMR_OK;
+    const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
+    if (f.tiles16)
         hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint16_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           p->H, p->groupRows, p->groupRowBase, p->blockCols, p->tiles16, p->blockMask,
-                           p->denseItems, p->numDenseItems, P);
+                           f.H, f.groupRows, f.groupRowBase, f.blockCols, f.tiles16, f.blockMask, f.items,
+                           f.numItems, P);
     else
         hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint32_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           p->H, p->groupRows, p->groupRowBase, p->blockCols, p->tiles32, p->blockMask,
-                           p->denseItems, p->numDenseItems, P);
+                           f.H, f.groupRows, f.groupRowBase, f.blockCols, f.tiles32, f.blockMask, f.items,
+                           f.numItems, P);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
 
 int launchDense32(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P,
                   hipStream_t s) {
-    if (p->numDenseItems == 0) return BSMR_OK;
-    const uint32_t wgs = (p->numDenseItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
-    if (p->tiles16)
-        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint16_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, p->H,
-                           p->groupRows, p->groupRowBase, p->blockCols, p->tiles16, p->blockMask,
-                           p->denseItems, p->numDenseItems, P);
+    const DenseFormat& f = p->fmt[0];
+    if (f.numItems == 0) return BSMR_OK;
+    const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
+    if (f.tiles16)
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint16_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
+                           f.groupRows, f.groupRowBase, f.blockCols, f.tiles16, f.blockMask, f.items,
+                           f.numItems, P);
     else
-        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint32_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, p->H,
-                           p->groupRows, p->groupRowBase, p->blockCols, p->tiles32, p->blockMask,
-                           p->denseItems, p->numDenseItems, P);
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint32_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
+                           f.groupRows, f.groupRowBase, f.blockCols, f.tiles32, f.blockMask, f.items,
+                           f.numItems, P);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -254,6 +301,10 @@ int checkCall(const bsmr_plan* p, uint32_t K, const void* A, const void* B, cons
     return BSMR_OK;
 }
 
+inline bool needsWorkspace(const bsmr_plan* p, int mode) {
+    return mode != BSMR_COMPUTE_F32 && p->fmt[0].numItems && !p->convertInKernel;
+}
+
 int reserve(bsmr_plan* p, uint32_t K) {
     if (p->reservedK >= K && p->A16 && p->B16) return BSMR_OK;
     if (p->A16) (void)hipFree(p->A16);
@@ -278,18 +329,16 @@ int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P
             st = mode == BSMR_COMPUTE_F16 ? launchDenseCvt<0>(p, K, A, B, P, s) : launchDenseCvt<1>(p, K, A, B, P, s);
             if (st != BSMR_OK) return st;
         }
-    } else {
-        if (p->numDenseItems) {
-            if (which & 1) {
-                st = mode == BSMR_COMPUTE_F16 ? launchConvert<0>(p, K, A, B, p->A16, p->B16, s)
-                                              : launchConvert<1>(p, K, A, B, p->A16, p->B16, s);
-                if (st != BSMR_OK) return st;
-            }
-            if (which & 2) {
-                st = mode == BSMR_COMPUTE_F16 ? launchDense16<0>(p, K, p->A16, p->B16, P, s)
-                                              : launchDense16<1>(p, K, p->A16, p->B16, P, s);
-                if (st != BSMR_OK) return st;
-            }
+    } else if (p->fmt[0].numItems) {
+        if (which & 1) {
+            st = mode == BSMR_COMPUTE_F16 ? launchConvert<0>(p, K, A, B, p->A16, p->B16, s)
+                                          : launchConvert<1>(p, K, A, B, p->A16, p->B16, s);
+            if (st != BSMR_OK) return st;
+        }
+        if (which & 2) {
+            st = mode == BSMR_COMPUTE_F16 ? launchDense16<0>(p, K, p->A16, p->B16, P, s)
+                                          : launchDense16<1>(p, K, p->A16, p->B16, P, s);
+            if (st != BSMR_OK) return st;
         }
     }
     if ((which & 4) && (st = launchSparse(p, K, A, B, P, s)) != BSMR_OK) return st;
@@ -409,7 +458,8 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
 
     try {
         bsmr::PackOptions opt;
-        opt.group = envInt("BSMR_DENSE_GROUP", 0);
+        const int forcedGroup = envInt("BSMR_DENSE_GROUP", 0);
+        opt.group = forcedGroup == 1 || forcedGroup == 2 || forcedGroup == 4 ? forcedGroup : 1;
         opt.blocksPerItem = envInt("BSMR_DENSE_BLOCKS_PER_WG", 32);
         opt.sparsePerItem = envInt("BSMR_SPARSE_ENTRIES_PER_WG", 256);
         opt.forceWideTiles = envInt("BSMR_FORCE_TILE32", 0) != 0;
@@ -424,13 +474,8 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         p->N = d->N;
         p->nnz = d->nnz;
         p->numPanels = P;
-        p->H = pk.H;
-        p->numBlocks = pk.numBlocks;
-        p->numTiles = pk.numTiles;
-        p->unionColumns = pk.unionColumns;
         p->numDenseEntries = pk.numDenseEntries;
         p->numSparseEntries = pk.numSparseEntries;
-        p->numDenseItems = (uint32_t)pk.denseItems.size();
         p->numSparseItems = (uint32_t)pk.sparseItems.size();
         p->sparseLpe = envInt("BSMR_SPARSE_LPE", 8);
         if (p->sparseLpe != 4 && p->sparseLpe != 8 && p->sparseLpe != 16) p->sparseLpe = 8;
@@ -438,21 +483,23 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         // full conversion moves 6 bytes per operand element; the in-kernel path reads each
         // gathered element as fp32 (4 B, A re-read per block) from a slower kernel
         const int cvt = envInt("BSMR_CONVERT_IN_KERNEL", -1);
-        p->convertInKernel = cvt >= 0 ? cvt != 0
-                                      : pk.unionColumns * 16ull < ((uint64_t)d->M + d->N) * 6ull;
+        p->convertInKernel = cvt >= 0 ? cvt != 0 : pk.unionColumns * 16ull < ((uint64_t)d->M + d->N) * 6ull;
 
-        st = upload(p->panelRows, pk.panelRows, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->groupRows, pk.groupRows, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->groupRowBase, pk.groupRowBase, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->blockCols, pk.blockCols, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->tiles16, pk.tiles16, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->tiles32, pk.tiles32, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->blockMask, pk.blockMask, p->indexBytes);
-        if (st == BSMR_OK) st = upload(p->denseItems, pk.denseItems, p->indexBytes);
+        st = uploadDense(p->fmt[0], pk, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->panelRows, pk.panelRows, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->entryCol, pk.entryCol, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->entryDst, pk.entryDst, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->entryRow, pk.entryRow, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->sparseItems, pk.sparseItems, p->indexBytes);
+
+        // second dense format (4 panels per group) for gather-bound calls
+        if (st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8) {
+            bsmr::PackedPlan pk4;
+            opt.group = 4;
+            st = bsmr::packPlan(d, opt, pk4);
+            if (st == BSMR_OK && pk4.unionColumns * 4 <= pk.unionColumns * 3)
+                st = uploadDense(p->fmt[1], pk4, p->indexBytes);
+        }
         if (st != BSMR_OK) {
             freePlanDevice(p);
             delete p;
@@ -477,16 +524,30 @@ int bsmr_plan_destroy(bsmr_plan* plan) {
 
 int bsmr_plan_get_stats(const bsmr_plan* p, bsmr_plan_stats* out) {
     if (!p || !out) return BSMR_ERR_INVALID_ARG;
+    const DenseFormat& f = p->fmt[0];
     out->num_row_panels = p->numPanels;
-    out->num_dense_blocks = p->numBlocks;
+    out->num_dense_blocks = f.numBlocks;
     out->num_dense_entries = p->numDenseEntries;
     out->num_sparse_entries = p->numSparseEntries;
-    out->dense_work_items = p->numDenseItems;
+    out->dense_work_items = f.numItems;
     out->sparse_work_items = p->numSparseItems;
     out->device_index_bytes = p->indexBytes;
-    out->group_size = p->H;
-    out->num_dense_tiles = p->numTiles;
-    out->union_columns = p->unionColumns;
+    out->group_size = f.H ? f.H : 1;
+    out->num_dense_tiles = f.numTiles;
+    out->union_columns = f.unionColumns;
+    out->grouped_group_size = p->fmt[1].H;
+    out->grouped_dense_tiles = p->fmt[1].numTiles;
+    out->grouped_union_columns = p->fmt[1].unionColumns;
+    return BSMR_OK;
+}
+
+int bsmr_plan_dense_choice(const bsmr_plan* plan, uint32_t K, uint32_t* group_size, uint64_t* tiles,
+                           uint64_t* union_columns) {
+    if (!plan) return BSMR_ERR_INVALID_ARG;
+    const DenseFormat& f = chooseFormat(plan, K);
+    if (group_size) *group_size = f.H ? f.H : 1;
+    if (tiles) *tiles = f.numTiles;
+    if (union_columns) *union_columns = f.unionColumns;
     return BSMR_OK;
 }
 
@@ -494,6 +555,7 @@ int bsmr_plan_reserve(bsmr_plan* plan, uint32_t K) {
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     BSMR_HIP(hipSetDevice(plan->device));
+    if (!plan->fmt[0].numItems || plan->convertInKernel) return BSMR_OK;
     return reserve(plan, K);
 }
 
@@ -502,9 +564,7 @@ int bsmr_sddmm(bsmr_plan* plan, uint32_t K, const float* A, const float* B, floa
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     BSMR_HIP(hipSetDevice(plan->device));
-    if (mode != BSMR_COMPUTE_F32 && plan->numDenseItems && !plan->convertInKernel &&
-        (st = reserve(plan, K)) != BSMR_OK)
-        return st;
+    if (needsWorkspace(plan, mode) && (st = reserve(plan, K)) != BSMR_OK) return st;
     return runPieces(plan, K, A, B, P, mode, static_cast<hipStream_t>(stream), 7);
 }
 
@@ -543,9 +603,7 @@ int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     if (st != BSMR_OK) return st;
     if (!out || iters <= 0 || warmup < 0) return BSMR_ERR_INVALID_ARG;
     BSMR_HIP(hipSetDevice(plan->device));
-    if (mode != BSMR_COMPUTE_F32 && plan->numDenseItems && !plan->convertInKernel &&
-        (st = reserve(plan, K)) != BSMR_OK)
-        return st;
+    if (needsWorkspace(plan, mode) && (st = reserve(plan, K)) != BSMR_OK) return st;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BSMR_HIP(hipEventCreate(&e0));
@@ -568,9 +626,8 @@ int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     for (int i = 0; i < warmup && st == BSMR_OK; ++i) st = runPieces(plan, K, A, B, P, mode, s, 7);
     bsmr_timing t{};
     if (st == BSMR_OK) st = timeLoop(7, t.total_ms);
-    if (st == BSMR_OK && mode != BSMR_COMPUTE_F32 && plan->numDenseItems && !plan->convertInKernel)
-        st = timeLoop(1, t.convert_ms);
-    if (st == BSMR_OK && plan->numDenseItems) st = timeLoop(2, t.dense_ms);
+    if (st == BSMR_OK && needsWorkspace(plan, mode)) st = timeLoop(1, t.convert_ms);
+    if (st == BSMR_OK && plan->fmt[0].numItems) st = timeLoop(2, t.dense_ms);
     if (st == BSMR_OK && plan->numSparseItems) st = timeLoop(4, t.sparse_ms);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

@@ -48,7 +48,9 @@ class PlanStats(C.Structure):
                 ("num_dense_entries", C.c_uint64), ("num_sparse_entries", C.c_uint64),
                 ("dense_work_items", C.c_uint64), ("sparse_work_items", C.c_uint64),
                 ("device_index_bytes", C.c_uint64), ("group_size", C.c_uint32),
-                ("num_dense_tiles", C.c_uint64), ("union_columns", C.c_uint64)]
+                ("num_dense_tiles", C.c_uint64), ("union_columns", C.c_uint64),
+                ("grouped_group_size", C.c_uint32), ("grouped_dense_tiles", C.c_uint64),
+                ("grouped_union_columns", C.c_uint64)]
 
 
 class Timing(C.Structure):
@@ -72,6 +74,8 @@ HIP_SYMBOLS = {
     "bsmr_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RphmDesc)]),
     "bsmr_plan_destroy": (C.c_int, [C.c_void_p]),
     "bsmr_plan_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
+    "bsmr_plan_dense_choice": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint64)]),
     "bsmr_plan_reserve": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bsmr_sddmm": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                              C.c_void_p]),
@@ -292,6 +296,12 @@ class Pipeline:
         s = PlanStats()
         _check(hip().bsmr_plan_get_stats(self.plan, C.byref(s)), "bsmr_plan_get_stats")
         return {k: getattr(s, k) for k, _ in PlanStats._fields_}
+
+    def dense_choice(self, K: int) -> dict:
+        """Dense format used by a call with inner dimension K."""
+        g, t, u = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+        _check(hip().bsmr_plan_dense_choice(self.plan, K, C.byref(g), C.byref(t), C.byref(u)), "dense_choice")
+        return {"group_size": g.value, "tiles": t.value, "union_columns": u.value}
 
 
 def sddmm_cpu(csr: CSR, K: int, A: np.ndarray, B: np.ndarray) -> np.ndarray:

@@ -86,6 +86,10 @@ typedef struct bsmr_plan_stats {
     uint32_t group_size;          /* row panels whose dense columns share one B gather (1, 2, 4) */
     uint64_t num_dense_tiles;     /* non-empty 16x16 (panel, block) tiles = MFMA tiles executed   */
     uint64_t union_columns;       /* B columns gathered per SDDMM by the dense path               */
+    /* second dense format (4 panels per group) kept for gather-bound calls; 0 = not built */
+    uint32_t grouped_group_size;
+    uint64_t grouped_dense_tiles;
+    uint64_t grouped_union_columns;
 } bsmr_plan_stats;
 
 /* Kernel timings of the last bsmr_sddmm_timed call, milliseconds per iteration. */
@@ -115,6 +119,10 @@ int bsmr_device_synchronize(int device);
 int bsmr_plan_create(bsmr_plan **out, int device, const bsmr_rphm_desc *desc);
 int bsmr_plan_destroy(bsmr_plan *plan);
 int bsmr_plan_get_stats(const bsmr_plan *plan, bsmr_plan_stats *out);
+/* Which dense format a call with inner dimension K uses (any out pointer may be NULL):
+ * panels per group, MFMA tiles executed, B columns gathered. */
+int bsmr_plan_dense_choice(const bsmr_plan *plan, uint32_t K, uint32_t *group_size,
+                           uint64_t *tiles, uint64_t *union_columns);
 
 /* Grow the plan's operand workspace for inner dimension K now (otherwise it
  * grows on first use, which allocates and therefore must not happen inside a

@@ -139,6 +139,29 @@ def test_plan_knobs(engine, oracle, monkeypatch, knobs, K):
             assert (err <= (K / 32 + 4) * 2.0 ** -23 * absdot[flags]).all()
             if "BSMR_DENSE_GROUP" in knobs:
                 assert pipe.plan_stats()["group_size"] == int(knobs["BSMR_DENSE_GROUP"])
+                assert pipe.dense_choice(K)["group_size"] == int(knobs["BSMR_DENSE_GROUP"])
+
+
+def test_grouped_format_is_chosen_for_gather_bound_calls(engine, oracle):
+    """A plan keeps a second dense format (4 panels per group) and uses it when the ungrouped
+    B gather would exceed ~200 MB; both formats give the same entries."""
+    rows, cols, ro, ci = synth.bernoulli(rows=1024, cols=4096, density=0.1, seed=4)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    pipe = engine.Pipeline(csr, alpha=0.3, delta=0.0, device=0)
+    st = pipe.plan_stats()
+    assert st["group_size"] == 1 and st["grouped_group_size"] == 4
+    assert st["grouped_union_columns"] * 4 <= st["union_columns"] * 3
+    assert pipe.dense_choice(32)["group_size"] == 1       # 13 MB of gather
+    assert pipe.dense_choice(512)["group_size"] == 4      # 214 MB of gather
+    for K in (32, 512):
+        A = engine.make_data(rows * K, 5489)
+        B = engine.make_data(cols * K, 5490)
+        got = run_hip(engine, pipe, K, A, B, 0)
+        want = oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B)
+        assert oracle.check_data(want, got)[0] == 0
+        model = oracle.dense_lowp_model(2, rows, K, ro, ci, A, B)
+        absdot = oracle.sddmm_f64(rows, K, ro, ci, np.abs(A), np.abs(B))
+        assert (np.abs(got - model) <= (K / 32 + 4) * 2.0 ** -23 * absdot).all()
 
 
 def test_output_indexing_is_exact(engine, oracle):
