@@ -256,11 +256,23 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     loadTiles(item.first, maskCur, tileCur);
     if (numBatches > 1) loadMeta(item.first + NBW, colsNext, maskNext);
 
+    // The masked scatter of a batch is deferred by one batch: the stores are issued
+    // right after the barrier, together with the next gather, so that their
+    // completion (which the barrier's vmcnt(0) has to wait for - gfx950 has one
+    // counter for loads and stores) overlaps the gather latency instead of adding to it.
+    f32x4 pendAcc[MINE];
+    TileRaw pendTile[MINE];
+    uint32_t pendBits = 0;  // wave-uniform: bit m = pendAcc[m] holds results to write
+
     for (uint32_t it = 0; it < numBatches; ++it) {
         const uint32_t b0 = item.first + it * NBW;
         // batch `it` has landed (every wave drains its own DMA, then all meet); the
         // other buffer is free because every wave finished batch it-1 before arriving.
         __syncthreads();
+#pragma unroll
+        for (uint32_t m = 0; m < MINE; ++m)
+            if (pendBits & (1u << m)) scatterTile<TileT>(pendAcc[m], pendTile[m], rowBase, P);
+        pendBits = 0;
         if (it + 1 < numBatches) {
             issueGather((it + 1) & 1u, colsNext);
             loadTiles(b0 + NBW, maskNext, tileNext);
@@ -283,7 +295,9 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
                 const u32x4 bv = *reinterpret_cast<const u32x4*>(bCol + (((4u * s + g) ^ (r & SW)) << 4));
                 acc = mfma16<MODE>(a[s], bv, acc);
             }
-            scatterTile<TileT>(acc, tileCur[m], rowBase, P);
+            pendAcc[m] = acc;
+            pendTile[m] = tileCur[m];
+            pendBits |= 1u << m;
         }
 #pragma unroll
         for (uint32_t m = 0; m < MINE; ++m) tileCur[m] = tileNext[m];
@@ -292,6 +306,9 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
         maskCur = maskNext;
         maskNext = maskAfter;
     }
+#pragma unroll
+    for (uint32_t m = 0; m < MINE; ++m)
+        if (pendBits & (1u << m)) scatterTile<TileT>(pendAcc[m], pendTile[m], rowBase, P);
 }
 
 // ---------------------------------------------------------------------------
