@@ -79,7 +79,7 @@ def cpu_baseline(rows, cols, ro, ci, K, A, B, budget_s=12.0):
         call()
         passes += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or passes >= 200:
+        if dt >= budget_s or passes >= 20000:
             break
     gflops = 2.0 * ci.size * K * passes / dt / 1e9
     return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": int(lib.oracle_num_threads()),
@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--workload", default="nips_k128_dense", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -111,13 +113,16 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29512")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     gen, kwargs, K, alpha, delta = WORKLOADS[args.workload]
     mode = {"f16": eng.COMPUTE_F16, "bf16": eng.COMPUTE_BF16, "f32": eng.COMPUTE_F32}[args.mode]
-    if world > 1:
+    if sharded:
         import shard
         # weak scaling: rank r owns row-stacked copy r of the workload pattern (own seed)
         def make_pattern(r):

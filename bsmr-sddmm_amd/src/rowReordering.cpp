@@ -18,9 +18,10 @@
 //
 // Numerics: sums of squares are integers (64-bit here; the reference's 32-bit
 // sums overflow on very large clusters); norms, quotients and the min/max sums
-// are fp32, accumulated in ascending bin order (the reference uses a block-wide
-// tree, so rows whose similarity sits within rounding of alpha may fall on the
-// other side; any permutation is valid for SDDMM parity).
+// are fp32, accumulated over the row's bins in ascending order plus one exact
+// integer remainder term (see similarity()).  The reference sums all bins with a
+// block-wide tree, so rows whose similarity sits within rounding of alpha may
+// fall on the other side; any permutation is valid for SDDMM parity.
 
 #include <algorithm>
 #include <chrono>
@@ -51,6 +52,7 @@ struct RowEncodings {
     std::vector<size_t> offsets;  // rows + 1
     std::vector<BinCount> items;  // sorted by bin inside a row
     std::vector<UIN> dispersion;  // 0 for empty rows
+    std::vector<uint64_t> squares; // sum of count^2 per row
     const BinCount* begin(UIN row) const { return items.data() + offsets[row]; }
     const BinCount* end(UIN row) const { return items.data() + offsets[row + 1]; }
 };
@@ -60,6 +62,7 @@ RowEncodings buildEncodings(const sparseMatrix::CSR<float>& m, const UIN binWidt
     RowEncodings enc;
     enc.offsets.assign(static_cast<size_t>(rows) + 1, 0);
     enc.dispersion.assign(rows, 0);
+    enc.squares.assign(rows, 0);
     std::vector<UIN> numBins(rows, 0);
     // pass 1: number of touched bins per row
 #pragma omp parallel
@@ -89,28 +92,30 @@ RowEncodings buildEncodings(const sparseMatrix::CSR<float>& m, const UIN binWidt
             for (UIN i = b; i < e; ++i) bins.push_back(m.colIndices()[i] / binWidth);
             std::sort(bins.begin(), bins.end());
             BinCount* out = enc.items.data() + enc.offsets[r];
-            uint64_t slack = 0;
+            uint64_t slack = 0, sq = 0;
             size_t n = 0;
             for (size_t i = 0; i < bins.size();) {
                 size_t j = i;
                 while (j < bins.size() && bins[j] == bins[i]) ++j;
                 out[n++] = BinCount{bins[i], static_cast<UIN>(j - i)};
                 slack += binWidth - static_cast<UIN>(j - i);
+                sq += static_cast<uint64_t>(j - i) * (j - i);
                 i = j;
             }
             // sum over touched bins of (width - count)  +  nnz * #touched bins
             enc.dispersion[r] = static_cast<UIN>(slack + static_cast<uint64_t>(e - b) * n);
+            enc.squares[r] = sq;
         }
     }
     return enc;
 }
 
-// Running representative of one cluster: dense counts + sorted list of touched bins.
+// Running representative of one cluster: dense counts + list of touched bins.
 struct Representative {
     std::vector<UIN> count;     // numBins, zero outside `bins`
-    std::vector<UIN> bins;      // ascending
-    std::vector<UIN> scratch;
-    uint64_t sumSquares = 0;
+    std::vector<UIN> bins;      // touched bins, in order of first touch
+    uint64_t sumSquares = 0;    // sum of count^2
+    uint64_t total = 0;         // sum of count
 
     explicit Representative(size_t numBins) : count(numBins, 0) {}
 
@@ -118,6 +123,7 @@ struct Representative {
         for (const UIN b : bins) count[b] = 0;
         bins.clear();
         sumSquares = 0;
+        total = 0;
     }
 
     // rep += row; returns (via newBins) the bins that were empty before.
@@ -127,39 +133,35 @@ struct Representative {
             const uint64_t old = count[it->bin];
             if (old == 0) newBins.push_back(it->bin);
             sumSquares += 2 * old * it->count + static_cast<uint64_t>(it->count) * it->count;
+            total += it->count;
             count[it->bin] += it->count;
         }
-        if (!newBins.empty()) {
-            scratch.resize(bins.size() + newBins.size());
-            std::merge(bins.begin(), bins.end(), newBins.begin(), newBins.end(), scratch.begin());
-            bins.swap(scratch);
-        }
+        bins.insert(bins.end(), newBins.begin(), newBins.end());
     }
 };
 
-// Normalised weighted Jaccard similarity of the representative and one row.
-inline float similarity(const Representative& rep, const BinCount* rb, const BinCount* re) {
-    uint64_t rowSquares = 0;
-    for (const BinCount* it = rb; it != re; ++it)
-        rowSquares += static_cast<uint64_t>(it->count) * it->count;
+// Normalised weighted Jaccard similarity of the representative x and one row y:
+//   sum_b min(x_b/|x|, y_b/|y|) / sum_b max(x_b/|x|, y_b/|y|).
+// Only the row's bins are visited (ascending): bins touched by the representative
+// alone contribute x_b/|x| to the max-sum, and their total is (T - sum_{b in row} x_b)/|x|
+// with T = sum_b x_b an exact integer - O(|row|) instead of O(|rep| + |row|).
+inline float similarity(const Representative& rep, const BinCount* rb, const BinCount* re,
+                        uint64_t rowSquares) {
     if (rep.sumSquares == 0 && rowSquares == 0) return 1.0f;
     if (rep.sumSquares == 0 || rowSquares == 0) return 0.0f;
     const float normRep = std::sqrt(static_cast<float>(rep.sumSquares));
     const float normRow = std::sqrt(static_cast<float>(rowSquares));
-    float minSum = 0.0f, maxSum = 0.0f;
-    // ascending merge over the union of touched bins
-    size_t i = 0;
-    const size_t nRep = rep.bins.size();
-    const BinCount* it = rb;
-    while (i < nRep || it != re) {
-        const UIN binRep = i < nRep ? rep.bins[i] : NULL_VALUE;
-        const UIN binRow = it != re ? it->bin : NULL_VALUE;
-        float x = 0.0f, y = 0.0f;
-        if (binRep <= binRow) { x = static_cast<float>(rep.count[binRep]) / normRep; ++i; }
-        if (binRow <= binRep) { y = static_cast<float>(it->count) / normRow; ++it; }
+    float minSum = 0.0f, maxShared = 0.0f;
+    uint64_t repInRow = 0;
+    for (const BinCount* it = rb; it != re; ++it) {
+        const UIN c = rep.count[it->bin];
+        const float x = static_cast<float>(c) / normRep;
+        const float y = static_cast<float>(it->count) / normRow;
         minSum += std::fmin(x, y);
-        maxSum += std::fmax(x, y);
+        maxShared += std::fmax(x, y);
+        repInRow += c;
     }
+    const float maxSum = maxShared + static_cast<float>(rep.total - repInRow) / normRep;
     return minSum / maxSum;
 }
 
@@ -230,7 +232,7 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
 
     Representative rep(numBins);
     std::vector<UIN> seenBy(rows, 0);  // last cluster id that queued this position
-    std::vector<UIN> newBins;
+    std::vector<UIN> newBins, pending;
     std::priority_queue<UIN, std::vector<UIN>, std::greater<UIN>> candidates;
     const bool scanEverything = !(alpha >= 0.0f);  // negative alpha accepts disjoint rows too
 
@@ -257,21 +259,52 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
         cluster[start] = clusterId;
         rep.clear();
         rep.add(enc.begin(order[start]), enc.end(order[start]), newBins);
-        if (scanEverything) {
+        // When the representative's bins already reach most of the remaining rows the
+        // inverted index only adds work: scan every unassigned row instead, evaluating
+        // the similarities of a chunk in parallel against the current representative
+        // (rows before the first accepted one of a chunk were judged with the right
+        // representative; the rest of the chunk is re-judged after the merge).
+        bool scanAll = scanEverything;
+        if (!scanAll) {
+            size_t reach = 0;
+            for (const UIN b : newBins) reach += invLen[b];
+            scanAll = reach >= static_cast<size_t>(rows - start);
+        }
+        if (scanAll) {
+            pending.clear();
             for (UIN pos = start + 1; pos < rows; ++pos)
-                if (cluster[pos] == NULL_VALUE) candidates.push(pos);
+                if (cluster[pos] == NULL_VALUE) pending.push_back(pos);
+            constexpr size_t kChunk = 512;
+            size_t i = 0;
+            while (i < pending.size()) {
+                const size_t n = std::min(kChunk, pending.size() - i);
+                long long firstHit = static_cast<long long>(n);
+#pragma omp parallel for schedule(static) reduction(min : firstHit) if (n >= 64)
+                for (long long j = 0; j < static_cast<long long>(n); ++j) {
+                    const UIN row = order[pending[i + j]];
+                    if (similarity(rep, enc.begin(row), enc.end(row), enc.squares[row]) > alpha)
+                        firstHit = std::min(firstHit, j);
+                }
+                if (firstHit == static_cast<long long>(n)) {
+                    i += n;
+                    continue;
+                }
+                const UIN pos = pending[i + firstHit];
+                cluster[pos] = clusterId;
+                rep.add(enc.begin(order[pos]), enc.end(order[pos]), newBins);
+                i += static_cast<size_t>(firstHit) + 1;
+            }
         } else {
             for (const UIN b : newBins) enqueueBin(b, start, clusterId);
-        }
-        while (!candidates.empty()) {
-            const UIN pos = candidates.top();
-            candidates.pop();
-            const UIN row = order[pos];
-            if (similarity(rep, enc.begin(row), enc.end(row)) > alpha) {
-                cluster[pos] = clusterId;
-                rep.add(enc.begin(row), enc.end(row), newBins);
-                if (!scanEverything)
+            while (!candidates.empty()) {
+                const UIN pos = candidates.top();
+                candidates.pop();
+                const UIN row = order[pos];
+                if (similarity(rep, enc.begin(row), enc.end(row), enc.squares[row]) > alpha) {
+                    cluster[pos] = clusterId;
+                    rep.add(enc.begin(row), enc.end(row), newBins);
                     for (const UIN b : newBins) enqueueBin(b, pos, clusterId);
+                }
             }
         }
         // the first row the cluster left behind seeds the next one

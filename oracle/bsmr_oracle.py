@@ -119,7 +119,9 @@ def encodings(rows, cols, ro, ci, bs):
 
 def similarity(rep, cmp_):
     # :235-293.  Integer sums of squares; fp32 norms, quotients and sums.
-    # Summation order here: ascending bin index (the GPU uses a block tree).
+    # Summation order (the GPU uses a block tree over all bins): the compared row's
+    # bins in ascending order; bins touched by the representative alone add
+    # (T - sum_{b in row} rep_b) / |rep| to the max-sum in one term, T = sum(rep) exact.
     sx = int(np.sum(rep * rep))
     sy = int(np.sum(cmp_ * cmp_))
     if sx == 0 and sy == 0:
@@ -130,11 +132,14 @@ def similarity(rep, cmp_):
     ny = np.sqrt(np.float32(sy))
     mn = np.float32(0.0)
     mx = np.float32(0.0)
-    for b in np.nonzero((rep > 0) | (cmp_ > 0))[0]:
+    rep_in_row = 0
+    for b in np.nonzero(cmp_ > 0)[0]:
         a = np.float32(rep[b]) / nx
         c = np.float32(cmp_[b]) / ny
         mn = np.float32(mn + min(a, c))
         mx = np.float32(mx + max(a, c))
+        rep_in_row += int(rep[b])
+    mx = np.float32(mx + np.float32(int(np.sum(rep)) - rep_in_row) / nx)
     return np.float32(mn / mx)
 
 
