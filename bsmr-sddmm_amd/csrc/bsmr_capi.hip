@@ -28,13 +28,17 @@ using bsmr::SparseItem;
 struct DenseFormat {
     uint32_t H = 0;  // 0 = absent
     uint32_t* groupRows = nullptr;
-    uint32_t* groupRowBase = nullptr;
+    uint32_t* rowBase = nullptr;   // DIRECT: per group row; STAGED: per item row (window base)
+    uint16_t* winLen = nullptr;    // STAGED only
+    uint32_t* winMask = nullptr;   // STAGED only
     uint32_t* blockCols = nullptr;
-    uint16_t* tiles16 = nullptr;
+    uint8_t* tiles8 = nullptr;     // STAGED destination tiles
+    uint16_t* tiles16 = nullptr;   // DIRECT
     uint32_t* tiles32 = nullptr;
     uint8_t* blockMask = nullptr;
     DenseItem* items = nullptr;
     uint32_t numItems = 0;
+    bool stageInLds = false;       // assemble the row windows in LDS and write them out coalesced
     uint64_t numBlocks = 0, numTiles = 0, unionColumns = 0;
 };
 
@@ -122,7 +126,8 @@ int envInt(const char* name, int fallback) {
 
 void freePlanDevice(bsmr_plan* p) {
     for (DenseFormat& f : p->fmt) {
-        void* ptrs[] = {f.groupRows, f.groupRowBase, f.blockCols, f.tiles16, f.tiles32, f.blockMask, f.items};
+        void* ptrs[] = {f.groupRows, f.rowBase, f.winLen, f.winMask, f.blockCols, f.tiles8,
+                        f.tiles16,   f.tiles32, f.blockMask, f.items};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
         f = DenseFormat{};
@@ -139,8 +144,11 @@ int uploadDense(DenseFormat& f, const bsmr::PackedPlan& pk, uint64_t& bytes) {
     f.numTiles = pk.numTiles;
     f.unionColumns = pk.unionColumns;
     int st = upload(f.groupRows, pk.groupRows, bytes);
-    if (st == BSMR_OK) st = upload(f.groupRowBase, pk.groupRowBase, bytes);
+    if (st == BSMR_OK) st = upload(f.rowBase, pk.rowBase, bytes);
+    if (st == BSMR_OK) st = upload(f.winLen, pk.winLen, bytes);
+    if (st == BSMR_OK) st = upload(f.winMask, pk.winMask, bytes);
     if (st == BSMR_OK) st = upload(f.blockCols, pk.blockCols, bytes);
+    if (st == BSMR_OK) st = upload(f.tiles8, pk.tiles8, bytes);
     if (st == BSMR_OK) st = upload(f.tiles16, pk.tiles16, bytes);
     if (st == BSMR_OK) st = upload(f.tiles32, pk.tiles32, bytes);
     if (st == BSMR_OK) st = upload(f.blockMask, pk.blockMask, bytes);
@@ -170,25 +178,29 @@ int launchConvert(const bsmr_plan* p, uint32_t K, const float* A, const float* B
 
 // LDS-staged dense kernel for K = 32*KS: KS, H (panels per group) and NB (blocks
 // per workgroup batch) are compile-time.  LDS = 2 * NB * KS KiB.
-template <int KS, int H, int NB, int MODE, typename TileT>
+template <int KS, int H, int NB, int MODE, typename TileT, bool LDS_STAGE = false>
 int launchGroupsT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, const TileT* tiles, float* P,
                   hipStream_t s) {
-    auto kernel = bsmr::denseGroups<KS, H, NB, MODE, TileT>;
-    const size_t lds = (size_t)2 * NB * 1024u * KS;  // double-buffered batch of NB blocks
-    static bool raised = false;                      // per instantiation
+    auto kernel = bsmr::denseGroups<KS, H, NB, MODE, TileT, LDS_STAGE>;
+    // double-buffered batch of NB blocks (+ one 256-float window per group row when staged in LDS)
+    const size_t lds = (size_t)2 * NB * 1024u * KS + (LDS_STAGE ? (size_t)H * 16u * 1024u : 0u);
+    static bool raised = false;  // per instantiation
     if (lds > 64 * 1024 && !raised) {
         BSMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         raised = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(f.numItems), dim3(bsmr::kThreads), lds, s, A16, B16, f.groupRows,
-                       f.groupRowBase, f.blockCols, tiles, f.blockMask, f.items, P);
+    hipLaunchKernelGGL(kernel, dim3(f.numItems), dim3(bsmr::kThreads), lds, s, A16, B16, f.groupRows, f.rowBase,
+                       f.winLen, f.winMask, f.blockCols, tiles, f.blockMask, f.items, P);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
 
 template <int KS, int H, int NB, int MODE>
 int launchGroups(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+    if (f.tiles8)
+        return f.stageInLds ? launchGroupsT<KS, H, NB, MODE, uint8_t, true>(f, A16, B16, f.tiles8, P, s)
+                            : launchGroupsT<KS, H, NB, MODE, uint8_t, false>(f, A16, B16, f.tiles8, P, s);
     return f.tiles16 ? launchGroupsT<KS, H, NB, MODE, uint16_t>(f, A16, B16, f.tiles16, P, s)
                      : launchGroupsT<KS, H, NB, MODE, uint32_t>(f, A16, B16, f.tiles32, P, s);
 }
@@ -217,14 +229,18 @@ int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uin
     default: break;
     }
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
-    if (f.tiles16)
+    if (f.tiles8)
+        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint8_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A16,
+                           B16, K, f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items,
+                           f.numItems, P);
+    else if (f.tiles16)
         hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint16_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A16,
-                           B16, K, f.H, f.groupRows, f.groupRowBase, f.blockCols, f.tiles16, f.blockMask,
-                           f.items, f.numItems, P);
+                           B16, K, f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items,
+                           f.numItems, P);
     else
         hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint32_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A16,
-                           B16, K, f.H, f.groupRows, f.groupRowBase, f.blockCols, f.tiles32, f.blockMask,
-                           f.items, f.numItems, P);
+                           B16, K, f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items,
+                           f.numItems, P);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -235,14 +251,15 @@ int launchDenseCvt(const bsmr_plan* p, uint32_t K, const float* A, const float* 
     const DenseFormat& f = p->fmt[0];
     if (f.numItems == 0) return BSMR_OK;
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
-    if (f.tiles16)
+    if (f.tiles8)
+        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint8_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items, f.numItems, P);
+    else if (f.tiles16)
         hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint16_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           f.H, f.groupRows, f.groupRowBase, f.blockCols, f.tiles16, f.blockMask, f.items,
-                           f.numItems, P);
+                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items, f.numItems, P);
     else
         hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint32_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           f.H, f.groupRows, f.groupRowBase, f.blockCols, f.tiles32, f.blockMask, f.items,
-                           f.numItems, P);
+                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items, f.numItems, P);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -252,14 +269,15 @@ int launchDense32(const bsmr_plan* p, uint32_t K, const float* A, const float* B
     const DenseFormat& f = p->fmt[0];
     if (f.numItems == 0) return BSMR_OK;
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
-    if (f.tiles16)
+    if (f.tiles8)
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint8_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
+                           f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items, f.numItems, P);
+    else if (f.tiles16)
         hipLaunchKernelGGL(bsmr::denseGroupsF32<uint16_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
-                           f.groupRows, f.groupRowBase, f.blockCols, f.tiles16, f.blockMask, f.items,
-                           f.numItems, P);
+                           f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items, f.numItems, P);
     else
         hipLaunchKernelGGL(bsmr::denseGroupsF32<uint32_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
-                           f.groupRows, f.groupRowBase, f.blockCols, f.tiles32, f.blockMask, f.items,
-                           f.numItems, P);
+                           f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items, f.numItems, P);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -463,6 +481,11 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         opt.blocksPerItem = envInt("BSMR_DENSE_BLOCKS_PER_WG", 32);
         opt.sparsePerItem = envInt("BSMR_SPARSE_ENTRIES_PER_WG", 256);
         opt.forceWideTiles = envInt("BSMR_FORCE_TILE32", 0) != 0;
+        opt.columnOrder = envInt("BSMR_COLUMN_ORDER", 1) != 0;
+        // 0 = 16/32-bit offsets from the row's first dense entry; 1 = 8-bit window offsets,
+        // scattered; 2 = 8-bit window offsets, assembled in LDS and stored coalesced
+        const int outputMode = envInt("BSMR_OUTPUT_MODE", 1);
+        opt.staged = outputMode != 0;
         bsmr::PackedPlan pk;
         st = bsmr::packPlan(d, opt, pk);
         if (st != BSMR_OK) return st;
@@ -486,6 +509,7 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         p->convertInKernel = cvt >= 0 ? cvt != 0 : pk.unionColumns * 16ull < ((uint64_t)d->M + d->N) * 6ull;
 
         st = uploadDense(p->fmt[0], pk, p->indexBytes);
+        p->fmt[0].stageInLds = outputMode == 2;
         if (st == BSMR_OK) st = upload(p->panelRows, pk.panelRows, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->entryCol, pk.entryCol, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->entryDst, pk.entryDst, p->indexBytes);
@@ -499,6 +523,7 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
             st = bsmr::packPlan(d, opt, pk4);
             if (st == BSMR_OK && pk4.unionColumns * 4 <= pk.unionColumns * 3)
                 st = uploadDense(p->fmt[1], pk4, p->indexBytes);
+            p->fmt[1].stageInLds = outputMode == 2;
         }
         if (st != BSMR_OK) {
             freePlanDevice(p);

@@ -3,15 +3,28 @@
 // bsmr_plan_create.
 //
 // Dense part.  H consecutive row panels form a row GROUP.  For every group the
-// union of its panels' dense columns is ordered by entry count (descending, ties
-// by column id) and cut into 16-column blocks.  A block stores
-//   blockCols [16]          column ids (padding -> column 0, never written)
-//   tiles     [H][256]      per panel: row-relative CSR offsets in accumulator
-//                           (lane-major) order, all-ones = no entry
-//   blockMask               bit h set iff tiles[h] holds an entry
+// union of its panels' dense columns is ordered (by column id by default: an
+// XCD then works on one column range of B, and a workgroup's outputs for one
+// row are neighbours in P) and cut into 16-column blocks.  A block stores
+//   blockCols [16]      column ids (padding -> column 0, never written)
+//   blockMask           bit h set iff panel h of the group has an entry in the block
+//   tiles     [H][256]  per panel the destination of every accumulator element, in
+//                       accumulator (lane-major) order: element [4*lane + i] belongs
+//                       to tile row 4*(lane>>4)+i, tile column lane&15.
 // An entry (row i of panel p, column j) appears in the tile of (p, j) only if
 // column j is in panel p's OWN dense list: entries of sparse columns stay on the
 // sparse path even when another panel of the group made column j dense.
+//
+// Two destination encodings:
+//   STAGED (default): a work item (run of blocks of one group) writes, for every
+//     row, into a window of < 255 consecutive entries of P.  Tiles hold 8-bit
+//     offsets into that window (0xFF = none); the kernel assembles the windows in
+//     LDS and writes them out with coalesced stores, guided by a per-row ownership
+//     bitmap (window positions owned by the sparse path or by other items are
+//     skipped).  Items are cut so that every window fits.
+//   DIRECT (fallback when a single block already spans >= 255 entries of some row,
+//     e.g. CSR rows whose columns are not sorted): 16-bit (or 32-bit) offsets from
+//     the row's first dense entry, scattered straight to P.
 //
 // Sparse part: the reference's three arrays, with the relative row packed to a byte.
 #pragma once
@@ -27,21 +40,27 @@
 namespace bsmr {
 
 struct PackOptions {
-    int group = 0;            // panels per group: 1, 2 or 4; 0 = choose by estimated traffic
-    int blocksPerItem = 16;   // dense blocks per workgroup item
+    int group = 1;            // panels per group: 1, 2 or 4
+    int blocksPerItem = 32;   // dense blocks per workgroup item (upper bound)
     int sparsePerItem = 256;  // sparse entries per workgroup item
     bool forceWideTiles = false;
+    bool columnOrder = true;  // blocks in column-id order, items sorted by first column
+    bool staged = true;       // try the staged (LDS window) destination encoding
 };
 
 struct PackedPlan {
     uint32_t H = 1;
     uint32_t numGroups = 0;
+    bool staged = false;
     std::vector<uint32_t> panelRows;      // [P*16]   (sparse kernel)
     std::vector<uint32_t> groupRows;      // [G*16H]
-    std::vector<uint32_t> groupRowBase;   // [G*16H]
+    std::vector<uint32_t> rowBase;        // DIRECT: [G*16H] per group row; STAGED: [items*16H] window base
+    std::vector<uint16_t> winLen;         // STAGED: [items*16H] window length (0 = row unused by the item)
+    std::vector<uint32_t> winMask;        // STAGED: [items*16H*8] ownership bitmap of the window
     std::vector<uint32_t> blockCols;      // [NB*16]
-    std::vector<uint16_t> tiles16;        // [NB*H*256] or empty
-    std::vector<uint32_t> tiles32;        // [NB*H*256] or empty
+    std::vector<uint8_t> tiles8;          // STAGED: [NB*H*256]
+    std::vector<uint16_t> tiles16;        // DIRECT
+    std::vector<uint32_t> tiles32;        // DIRECT, rows with >= 65535 entries
     std::vector<uint8_t> blockMask;       // [NB]
     std::vector<DenseItem> denseItems;
     std::vector<uint32_t> entryCol, entryDst;
@@ -50,6 +69,9 @@ struct PackedPlan {
     uint64_t numBlocks = 0, numTiles = 0, numDenseEntries = 0, numSparseEntries = 0;
     uint64_t unionColumns = 0;            // sum over groups of distinct dense columns
 };
+
+constexpr uint32_t kWindow = 256;         // LDS floats per staged row
+constexpr uint32_t kWindowMax = 255;      // usable window length (0xFF is the null offset)
 
 namespace detail {
 
@@ -61,7 +83,8 @@ struct ColumnUse {
 
 // Distinct dense columns of the panels [p0, p0+h) with their per-panel slots.
 inline void unionColumns(const bsmr_rphm_desc* d, uint32_t p0, uint32_t h, uint32_t P,
-                         std::vector<ColumnUse>& out, std::unordered_map<uint32_t, uint32_t>& index) {
+                         std::vector<ColumnUse>& out, std::unordered_map<uint32_t, uint32_t>& index,
+                         bool byColumnId) {
     out.clear();
     index.clear();
     for (uint32_t k = 0; k < h && p0 + k < P; ++k) {
@@ -84,40 +107,22 @@ inline void unionColumns(const bsmr_rphm_desc* d, uint32_t p0, uint32_t h, uint3
             out[it->second].slot[k] = (int32_t)t;
         }
     }
-    std::sort(out.begin(), out.end(), [](const ColumnUse& a, const ColumnUse& b) {
-        return a.count != b.count ? a.count > b.count : a.col < b.col;
-    });
+    if (byColumnId)
+        std::sort(out.begin(), out.end(), [](const ColumnUse& a, const ColumnUse& b) { return a.col < b.col; });
+    else
+        std::sort(out.begin(), out.end(), [](const ColumnUse& a, const ColumnUse& b) {
+            return a.count != b.count ? a.count > b.count : a.col < b.col;
+        });
 }
 
 }  // namespace detail
-
-// Estimated bytes one SDDMM moves for group size h (K = 128 proxy: 256 B per
-// gathered column, 512 B per non-empty tile).
-inline uint64_t estimateTraffic(const bsmr_rphm_desc* d, uint32_t h) {
-    const uint32_t P = d->num_row_panels;
-    std::vector<detail::ColumnUse> cols;
-    std::unordered_map<uint32_t, uint32_t> index;
-    uint64_t bytes = 0;
-    for (uint32_t p0 = 0; p0 < P; p0 += h) {
-        detail::unionColumns(d, p0, h, P, cols, index);
-        const uint64_t blocks = (cols.size() + 15) / 16;
-        bytes += blocks * 16 * 256;
-        for (uint64_t b = 0; b < blocks; ++b)
-            for (uint32_t k = 0; k < h; ++k) {
-                bool any = false;
-                for (uint64_t u = b * 16; u < std::min<uint64_t>(b * 16 + 16, cols.size()) && !any; ++u)
-                    any = cols[u].slot[k] >= 0;
-                bytes += any ? 512 : 0;
-            }
-    }
-    return bytes;
-}
 
 // Returns a bsmr_hip.h status.
 inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan& out) {
     const uint32_t P = d->num_row_panels;
     const uint64_t numRefBlocks = d->block_offsets[P];
     const uint64_t numSparse = d->sparse_value_offsets[P];
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
 
     for (uint32_t p = 0; p < P; ++p)
         if (d->block_offsets[p + 1] < d->block_offsets[p] ||
@@ -132,18 +137,18 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
         out.panelRows[i] = row;
     }
 
-    // rowBase of a panel row = smallest CSR index among its dense entries
+    // first dense entry of every panel row (base of the DIRECT offsets)
     std::vector<uint32_t> panelRowBase((size_t)P * 16, 0);
     uint32_t maxOffset = 0;
     out.numDenseEntries = 0;
     for (uint32_t p = 0; p < P; ++p) {
         uint32_t lo[16], hi[16];
-        for (int r = 0; r < 16; ++r) { lo[r] = 0xFFFFFFFFu; hi[r] = 0; }
+        for (int r = 0; r < 16; ++r) { lo[r] = kNone; hi[r] = 0; }
         for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b) {
             const uint32_t* tile = d->block_values + b * 256;
             for (uint32_t i = 0; i < 256; ++i) {
                 const uint32_t v = tile[i];
-                if (v == 0xFFFFFFFFu) continue;
+                if (v == kNone) continue;
                 if (v >= d->nnz) return BSMR_ERR_BAD_PLAN;
                 ++out.numDenseEntries;
                 lo[i >> 4] = std::min(lo[i >> 4], v);
@@ -151,7 +156,7 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
             }
         }
         for (int r = 0; r < 16; ++r) {
-            if (lo[r] == 0xFFFFFFFFu) continue;
+            if (lo[r] == kNone) continue;
             panelRowBase[(size_t)p * 16 + r] = lo[r];
             maxOffset = std::max(maxOffset, hi[r] - lo[r]);
         }
@@ -159,43 +164,35 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
     for (uint64_t i = 0; i < numRefBlocks * 16; ++i)
         if (d->dense_cols[i] > d->N) return BSMR_ERR_BAD_PLAN;
 
-    // ---- group size ---------------------------------------------------------
-    uint32_t H = opt.group == 1 || opt.group == 2 || opt.group == 4 ? (uint32_t)opt.group : 0;
-    // Default 1.  Grouping halves the gathered B bytes on the nips-like matrix
-    // (H=4: 345k -> 179k column gathers) but multiplies the per-tile work (tile
-    // loads, masked scatter stores), which is what the kernel is bound by at
-    // L2-resident sizes: measured 14.2 us (H=1) vs 18.9 us (H=4) on MI355X
-    // (profiles/r01_dense_ablation.md).  Kept selectable for HBM-resident operands.
-    if (H == 0) H = 1;
+    // ---- groups -------------------------------------------------------------
+    const uint32_t H = opt.group == 2 || opt.group == 4 ? (uint32_t)opt.group : 1u;
     out.H = H;
     const uint32_t G = (P + H - 1) / H;
+    const uint32_t R = 16 * H;  // rows per group
     out.numGroups = G;
-    out.groupRows.assign((size_t)G * 16 * H, out.panelRows.empty() ? 0 : out.panelRows[0]);
-    out.groupRowBase.assign((size_t)G * 16 * H, 0);
+    out.groupRows.assign((size_t)G * R, out.panelRows.empty() ? 0 : out.panelRows[0]);
     std::copy(out.panelRows.begin(), out.panelRows.end(), out.groupRows.begin());
-    std::copy(panelRowBase.begin(), panelRowBase.end(), out.groupRowBase.begin());
+    std::vector<uint32_t> groupRowBase((size_t)G * R, 0);
+    std::copy(panelRowBase.begin(), panelRowBase.end(), groupRowBase.begin());
 
-    // ---- dense blocks -------------------------------------------------------
-    const bool wide = opt.forceWideTiles || maxOffset >= 0xFFFFu;
+    // ---- dense blocks: columns, masks and absolute destinations -----------------
     std::vector<detail::ColumnUse> cols;
     std::unordered_map<uint32_t, uint32_t> index;
+    std::vector<uint32_t> absTiles;               // [NB*H*256] CSR index or kNone, lane-major
+    std::vector<uint32_t> groupFirstBlock(G + 1, 0);
     out.blockCols.clear();
     out.blockMask.clear();
-    out.tiles16.clear();
-    out.tiles32.clear();
-    out.denseItems.clear();
     out.unionColumns = 0;
-    const uint32_t perItem = (uint32_t)std::max(1, opt.blocksPerItem);
     for (uint32_t gi = 0; gi < G; ++gi) {
         const uint32_t p0 = gi * H;
-        detail::unionColumns(d, p0, H, P, cols, index);
+        detail::unionColumns(d, p0, H, P, cols, index, opt.columnOrder);
         out.unionColumns += cols.size();
         const uint32_t blocks = (uint32_t)((cols.size() + 15) / 16);
         const uint64_t firstBlock = out.blockMask.size();
+        groupFirstBlock[gi] = (uint32_t)firstBlock;
         out.blockCols.resize((firstBlock + blocks) * 16, 0);
         out.blockMask.resize(firstBlock + blocks, 0);
-        if (wide) out.tiles32.resize((firstBlock + blocks) * H * 256, 0xFFFFFFFFu);
-        else out.tiles16.resize((firstBlock + blocks) * H * 256, 0xFFFFu);
+        absTiles.resize((firstBlock + blocks) * H * 256, kNone);
         for (size_t u = 0; u < cols.size(); ++u) {
             const uint64_t b = firstBlock + u / 16;
             const uint32_t cc = (uint32_t)(u % 16);
@@ -207,23 +204,146 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
                 const uint32_t* tile = d->block_values + ((uint64_t)d->block_offsets[p] + t / 16) * 256;
                 for (uint32_t r = 0; r < 16; ++r) {
                     const uint32_t v = tile[r * 16 + t % 16];
-                    if (v == 0xFFFFFFFFu) continue;
-                    const uint32_t off = v - panelRowBase[(size_t)p * 16 + r];
+                    if (v == kNone) continue;
                     const uint32_t lane = (r >> 2) * 16 + cc, i = r & 3u;
-                    const size_t at = (b * H + k) * 256 + lane * 4 + i;
-                    if (wide) out.tiles32[at] = off;
-                    else out.tiles16[at] = (uint16_t)off;
+                    absTiles[(b * H + k) * 256 + lane * 4 + i] = v;
                     out.blockMask[b] |= (uint8_t)(1u << k);
                 }
             }
         }
-        for (uint32_t b = 0; b < blocks; b += perItem)
-            out.denseItems.push_back(
-                DenseItem{gi, (uint32_t)(firstBlock + b), std::min(perItem, blocks - b), 0});
     }
+    groupFirstBlock[G] = (uint32_t)out.blockMask.size();
     out.numBlocks = out.blockMask.size();
     out.numTiles = 0;
     for (const uint8_t m : out.blockMask) out.numTiles += __builtin_popcount(m);
+
+    // tile element -> group row: lane-major index e = 4*lane + i of panel k
+    auto rowOfElement = [](uint32_t k, uint32_t e) { return k * 16u + 4u * ((e >> 2) >> 4) + (e & 3u); };
+
+    // ---- work items + destination encoding ----------------------------------------
+    const uint32_t perItem = (uint32_t)std::max(1, opt.blocksPerItem);
+    out.denseItems.clear();
+    out.staged = opt.staged && !opt.forceWideTiles;
+    std::vector<uint32_t> itemLo;  // STAGED: [items*R] window base per item row (kNone = unused)
+    if (out.staged) {
+        std::vector<uint32_t> lo(R), hi(R), blo(R), bhi(R);
+        for (uint32_t gi = 0; gi < G && out.staged; ++gi) {
+            uint32_t itemFirst = groupFirstBlock[gi], count = 0;
+            std::fill(lo.begin(), lo.end(), kNone);
+            std::fill(hi.begin(), hi.end(), 0u);
+            auto closeItem = [&]() {
+                if (!count) return;
+                out.denseItems.push_back(DenseItem{gi, itemFirst, count, 0});
+                itemLo.insert(itemLo.end(), lo.begin(), lo.end());
+                std::fill(lo.begin(), lo.end(), kNone);
+                std::fill(hi.begin(), hi.end(), 0u);
+                count = 0;
+            };
+            for (uint32_t b = groupFirstBlock[gi]; b < groupFirstBlock[gi + 1]; ++b) {
+                std::fill(blo.begin(), blo.end(), kNone);
+                std::fill(bhi.begin(), bhi.end(), 0u);
+                for (uint32_t k = 0; k < H; ++k)
+                    for (uint32_t e = 0; e < 256; ++e) {
+                        const uint32_t v = absTiles[((size_t)b * H + k) * 256 + e];
+                        if (v == kNone) continue;
+                        const uint32_t row = rowOfElement(k, e);
+                        blo[row] = std::min(blo[row], v);
+                        bhi[row] = std::max(bhi[row], v);
+                    }
+                bool fits = count < perItem;
+                for (uint32_t r = 0; r < R; ++r) {
+                    if (blo[r] == kNone) continue;
+                    if (bhi[r] - blo[r] >= kWindowMax) out.staged = false;  // one block alone is too wide
+                    if (lo[r] != kNone && std::max(hi[r], bhi[r]) - std::min(lo[r], blo[r]) >= kWindowMax) fits = false;
+                }
+                if (!out.staged) break;
+                if (!fits) closeItem();
+                if (count == 0) itemFirst = b;
+                for (uint32_t r = 0; r < R; ++r) {
+                    if (blo[r] == kNone) continue;
+                    lo[r] = std::min(lo[r], blo[r]);
+                    hi[r] = std::max(hi[r], bhi[r]);
+                }
+                ++count;
+            }
+            closeItem();
+        }
+    }
+    if (out.staged) {
+        const size_t numItems = out.denseItems.size();
+        out.rowBase.assign(numItems * R, 0);
+        out.winLen.assign(numItems * R, 0);
+        out.winMask.assign(numItems * R * (kWindow / 32), 0);
+        out.tiles8.assign(out.numBlocks * H * 256, 0xFF);
+        out.tiles16.clear();
+        out.tiles32.clear();
+        for (size_t it = 0; it < numItems; ++it) {
+            const DenseItem& item = out.denseItems[it];
+            for (uint32_t r = 0; r < R; ++r)
+                if (itemLo[it * R + r] != kNone) out.rowBase[it * R + r] = itemLo[it * R + r];
+            for (uint32_t b = item.first; b < item.first + item.count; ++b)
+                for (uint32_t k = 0; k < H; ++k)
+                    for (uint32_t e = 0; e < 256; ++e) {
+                        const size_t at = ((size_t)b * H + k) * 256 + e;
+                        const uint32_t v = absTiles[at];
+                        if (v == kNone) continue;
+                        const uint32_t row = rowOfElement(k, e);
+                        const uint32_t off = v - itemLo[it * R + row];
+                        out.tiles8[at] = (uint8_t)off;
+                        out.winMask[(it * R + row) * (kWindow / 32) + off / 32] |= 1u << (off % 32);
+                        out.winLen[it * R + row] = std::max<uint16_t>(out.winLen[it * R + row], (uint16_t)(off + 1));
+                    }
+        }
+    } else {
+        out.denseItems.clear();
+        for (uint32_t gi = 0; gi < G; ++gi)
+            for (uint32_t b = groupFirstBlock[gi]; b < groupFirstBlock[gi + 1]; b += perItem)
+                out.denseItems.push_back(DenseItem{gi, b, std::min(perItem, groupFirstBlock[gi + 1] - b), 0});
+        out.rowBase = groupRowBase;
+        out.winLen.clear();
+        out.winMask.clear();
+        out.tiles8.clear();
+        const bool wide = opt.forceWideTiles || maxOffset >= 0xFFFFu;
+        out.tiles16.assign(wide ? 0 : absTiles.size(), 0xFFFFu);
+        out.tiles32.assign(wide ? absTiles.size() : 0, kNone);
+        for (uint32_t gi = 0; gi < G; ++gi)
+            for (uint32_t b = groupFirstBlock[gi]; b < groupFirstBlock[gi + 1]; ++b)
+                for (uint32_t k = 0; k < H; ++k)
+                    for (uint32_t e = 0; e < 256; ++e) {
+                        const size_t at = ((size_t)b * H + k) * 256 + e;
+                        const uint32_t v = absTiles[at];
+                        if (v == kNone) continue;
+                        const uint32_t off = v - groupRowBase[(size_t)gi * R + rowOfElement(k, e)];
+                        if (wide) out.tiles32[at] = off;
+                        else out.tiles16[at] = (uint16_t)off;
+                    }
+    }
+    if (opt.columnOrder) {
+        // workgroup i of XCD x takes item x*(n/8)+i: an XCD then sees one column range of B.
+        // The per-item arrays of the STAGED form are permuted along.
+        std::vector<uint32_t> order(out.denseItems.size());
+        for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            return out.blockCols[(size_t)out.denseItems[a].first * 16] <
+                   out.blockCols[(size_t)out.denseItems[b].first * 16];
+        });
+        std::vector<DenseItem> items(order.size());
+        for (size_t i = 0; i < order.size(); ++i) items[i] = out.denseItems[order[i]];
+        out.denseItems.swap(items);
+        if (out.staged) {
+            std::vector<uint32_t> rb(out.rowBase.size()), wm(out.winMask.size());
+            std::vector<uint16_t> wl(out.winLen.size());
+            for (size_t i = 0; i < order.size(); ++i) {
+                std::copy_n(out.rowBase.begin() + (size_t)order[i] * R, R, rb.begin() + i * R);
+                std::copy_n(out.winLen.begin() + (size_t)order[i] * R, R, wl.begin() + i * R);
+                std::copy_n(out.winMask.begin() + (size_t)order[i] * R * (kWindow / 32), R * (kWindow / 32),
+                            wm.begin() + i * R * (kWindow / 32));
+            }
+            out.rowBase.swap(rb);
+            out.winLen.swap(wl);
+            out.winMask.swap(wm);
+        }
+    }
 
     // ---- sparse residue -------------------------------------------------------
     out.entryCol.resize(numSparse);

@@ -21,11 +21,13 @@
 //    (ds_read_b128, 16 lanes = 16 columns at one k offset) are conflict-free.
 //  * The four waves of a workgroup split a group's work by panel: each wave
 //    keeps its own panel's A fragments in registers; B blocks are shared via LDS.
-//  * Mask + destinations: per (block, panel) one tile of 256 row-relative 16-bit
-//    offsets in accumulator (lane-major) order, 0xFFFF = no entry: 8 bytes per
-//    lane, independent of anything the wave computes (the reference stores a
-//    1 KiB row-major tile of absolute 32-bit indices per block).  Tiles that
-//    hold no entry are skipped through a per-block bit mask.
+//  * Mask + destinations: per (block, panel) one tile of 256 destinations in
+//    accumulator (lane-major) order - 4 bytes per lane in the staged form (8-bit
+//    offsets into a per-row window of P that the workgroup assembles in LDS and
+//    writes out coalesced), 8 or 16 bytes per lane in the direct form; independent
+//    of anything the wave computes (the reference stores a 1 KiB row-major tile of
+//    absolute 32-bit indices per block).  Tiles without entries are skipped
+//    through a per-block bit mask.  Layouts: csrc/plan_pack.hpp.
 //
 // Sparse residue (sparseEntries): K split over LPE lanes per entry (coalesced
 // 16-byte loads of the B column), A rows from LDS, butterfly reduction; exact
@@ -69,7 +71,9 @@ struct SparseItem {
 // items - consecutive blocks of one group, consecutive groups of one cluster,
 // which share B columns - hit the same L2.  Speed only; any placement is correct.
 __device__ __forceinline__ uint32_t xcdContiguous(uint32_t wg, uint32_t numWG) {
-    return (numWG & 7u) == 0 ? (wg & 7u) * (numWG >> 3) + (wg >> 3) : wg;
+    const uint32_t xcd = wg & 7u, idx = wg >> 3;
+    const uint32_t base = numWG >> 3, rem = numWG & 7u;  // XCD x owns base + (x < rem) items
+    return xcd * base + (xcd < rem ? xcd : rem) + idx;
 }
 
 // ---------------------------------------------------------------------------
@@ -115,6 +119,11 @@ template <> struct TileLoad<uint16_t> {
         const uint32_t w = i < 2 ? v[0] : v[1];
         return (i & 1) ? (w >> 16) : (w & 0xFFFFu);
     }
+};
+template <> struct TileLoad<uint8_t> {   // staged form: offsets into the item's per-row window
+    typedef uint32_t raw;
+    static constexpr uint32_t kNull = 0xFFu;
+    static __device__ __forceinline__ uint32_t get(const raw& v, int i) { return (v >> (8 * i)) & 0xFFu; }
 };
 template <> struct TileLoad<uint32_t> {
     typedef u32x4 raw;
@@ -165,12 +174,21 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f3
 // fragment of lane (c = l&15, g = l>>4) at K step s is piece 4s+g of column c:
 // the 16 lanes of a ds_read_b128 group hit 16 different 16-byte slots.
 // ---------------------------------------------------------------------------
-template <int KS, int H, int NBW, int MODE, typename TileT>
+template <int KS, int H, int NBW, int MODE, typename TileT, bool LDS_STAGE = false>
 __global__ void __launch_bounds__(kThreads)
 denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
-            const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ groupRowBase,
+            const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ rowBaseTable,
+            const uint16_t* __restrict__ winLen, const uint32_t* __restrict__ winMask,
             const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
             const uint8_t* __restrict__ blockMask, const DenseItem* __restrict__ items, float* __restrict__ P) {
+    // 8-bit tiles: offsets into a per-(item, row) window of P; rowBaseTable (window
+    //   base), winLen and winMask are indexed by item.  With LDS_STAGE the windows are
+    //   assembled in LDS and written out coalesced at the end (ownership bitmap =
+    //   winMask); without it the results are scattered straight into the windows.
+    // 16/32-bit tiles: offsets from the row's first dense entry; rowBaseTable is indexed
+    //   by group; results are scattered straight to P.
+    constexpr bool WINDOWED = sizeof(TileT) == 1;
+    constexpr bool STAGED = WINDOWED && LDS_STAGE;
     constexpr uint32_t K = 32u * KS;
     constexpr uint32_t PC = 4u * KS;                 // 16-byte pieces per column
     constexpr uint32_t SW = PC - 1u < 15u ? PC - 1u : 15u;
@@ -183,9 +201,11 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     typedef typename TileLoad<TileT>::raw TileRaw;
     static_assert(NBW <= 16 && (NBW & (NBW - 1)) == 0, "NBW must be a power of two <= 16");
 
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [2][NBW][blkBytes]
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [2][NBW][blkBytes] (+ [16H][256] floats)
+    float* stage = reinterpret_cast<float*>(lds + 2u * NBW * blkBytes);
 
-    const DenseItem item = items[xcdContiguous(blockIdx.x, gridDim.x)];
+    const uint32_t itemId = xcdContiguous(blockIdx.x, gridDim.x);
+    const DenseItem item = items[itemId];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t r = lane & 15u;   // tile row for A, tile column for B and C
@@ -204,7 +224,10 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     }
     uint32_t rowBase[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rowBase[i] = groupRowBase[rowSlot + 4u * g + i];
+    for (int i = 0; i < 4; ++i)
+        rowBase[i] = STAGED ? (h * 16u + 4u * g + i) * 256u   // float index of the row's LDS window
+                     : WINDOWED ? rowBaseTable[(size_t)itemId * (16u * H) + h * 16u + 4u * g + i]
+                                : rowBaseTable[rowSlot + 4u * g + i];
 
     // batch metadata: cols[q] of lane l = column (l & 15) of block b0 + 4q + (l >> 4);
     // maskReg of lane l = tile mask of block b0 + (l % NBW) (0 past the end)
@@ -269,10 +292,12 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
         // batch `it` has landed (every wave drains its own DMA, then all meet); the
         // other buffer is free because every wave finished batch it-1 before arriving.
         __syncthreads();
+        if constexpr (!STAGED) {
 #pragma unroll
-        for (uint32_t m = 0; m < MINE; ++m)
-            if (pendBits & (1u << m)) scatterTile<TileT>(pendAcc[m], pendTile[m], rowBase, P);
-        pendBits = 0;
+            for (uint32_t m = 0; m < MINE; ++m)
+                if (pendBits & (1u << m)) scatterTile<TileT>(pendAcc[m], pendTile[m], rowBase, P);
+            pendBits = 0;
+        }
         if (it + 1 < numBatches) {
             issueGather((it + 1) & 1u, colsNext);
             loadTiles(b0 + NBW, maskNext, tileNext);
@@ -295,9 +320,13 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
                 const u32x4 bv = *reinterpret_cast<const u32x4*>(bCol + (((4u * s + g) ^ (r & SW)) << 4));
                 acc = mfma16<MODE>(a[s], bv, acc);
             }
-            pendAcc[m] = acc;
-            pendTile[m] = tileCur[m];
-            pendBits |= 1u << m;
+            if constexpr (STAGED) {
+                scatterTile<TileT>(acc, tileCur[m], rowBase, stage);  // ds_write into the row windows
+            } else {
+                pendAcc[m] = acc;
+                pendTile[m] = tileCur[m];
+                pendBits |= 1u << m;
+            }
         }
 #pragma unroll
         for (uint32_t m = 0; m < MINE; ++m) tileCur[m] = tileNext[m];
@@ -306,9 +335,25 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
         maskCur = maskNext;
         maskNext = maskAfter;
     }
+    if constexpr (STAGED) {
+        // write the windows out: every wave takes rows wave, wave+4, ...; lanes walk the
+        // window, so a wave-instruction stores up to 256 contiguous bytes of P.  Window
+        // positions this item does not own (sparse path, other items) are skipped.
+        __syncthreads();
+        for (uint32_t row = wave; row < 16u * H; row += kWavesPerWG) {
+            const size_t slot = (size_t)itemId * (16u * H) + row;
+            const uint32_t len = winLen[slot];
+            const uint32_t base = rowBaseTable[slot];
+            for (uint32_t j = lane; j < len; j += kWave) {
+                const uint32_t word = winMask[slot * 8u + (j >> 5)];
+                if ((word >> (j & 31u)) & 1u) P[base + j] = stage[row * 256u + j];
+            }
+        }
+    } else {
 #pragma unroll
-    for (uint32_t m = 0; m < MINE; ++m)
-        if (pendBits & (1u << m)) scatterTile<TileT>(pendAcc[m], pendTile[m], rowBase, P);
+        for (uint32_t m = 0; m < MINE; ++m)
+            if (pendBits & (1u << m)) scatterTile<TileT>(pendAcc[m], pendTile[m], rowBase, P);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -337,7 +382,8 @@ denseGroupsAnyK(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B
             const typename TileLoad<TileT>::raw tile = loadTile<TileT>(tiles, (size_t)b * H + h, lane);
             uint32_t rowBase[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rowBase[i] = groupRowBase[slot + 4u * g + i];
+            for (int i = 0; i < 4; ++i)
+                rowBase[i] = groupRowBase[(sizeof(TileT) == 1 ? itemId * 16u * H + h * 16u : slot) + 4u * g + i];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (uint32_t s = 0; s < steps; ++s) {
                 const u32x4 av = *reinterpret_cast<const u32x4*>(aRow + s * 32u);
@@ -392,7 +438,8 @@ denseGroupsCvt(const float* __restrict__ A, const float* __restrict__ B, uint32_
             const typename TileLoad<TileT>::raw tile = loadTile<TileT>(tiles, (size_t)b * H + h, lane);
             uint32_t rowBase[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rowBase[i] = groupRowBase[slot + 4u * g + i];
+            for (int i = 0; i < 4; ++i)
+                rowBase[i] = groupRowBase[(sizeof(TileT) == 1 ? itemId * 16u * H + h * 16u : slot) + 4u * g + i];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (uint32_t s = 0; s < steps; ++s) {
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(aRow + s * 32u);
@@ -435,7 +482,8 @@ denseGroupsF32(const float* __restrict__ A, const float* __restrict__ B, uint32_
             const typename TileLoad<TileT>::raw tile = loadTile<TileT>(tiles, (size_t)b * H + h, lane);
             uint32_t rowBase[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rowBase[i] = groupRowBase[slot + 4u * g + i];
+            for (int i = 0; i < 4; ++i)
+                rowBase[i] = groupRowBase[(sizeof(TileT) == 1 ? itemId * 16u * H + h * 16u : slot) + 4u * g + i];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (uint32_t t = 0; t < steps; ++t) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(aRow + t * 16u);

@@ -115,6 +115,11 @@ def test_large_k_sparse_without_lds(engine, oracle):
     {"BSMR_CONVERT_IN_KERNEL": "1", "BSMR_DENSE_GROUP": "4"},
     {"BSMR_FORCE_TILE32": "1", "BSMR_DENSE_GROUP": "2"},
     {"BSMR_SPARSE_LPE": "4", "BSMR_SPARSE_ENTRIES_PER_WG": "32"}, {"BSMR_SPARSE_LPE": "16"},
+    {"BSMR_OUTPUT_MODE": "0"}, {"BSMR_OUTPUT_MODE": "0", "BSMR_COLUMN_ORDER": "0"},
+    {"BSMR_COLUMN_ORDER": "0"}, {"BSMR_OUTPUT_MODE": "0", "BSMR_DENSE_GROUP": "4"},
+    {"BSMR_OUTPUT_MODE": "2"}, {"BSMR_OUTPUT_MODE": "2", "BSMR_DENSE_GROUP": "4"},
+    {"BSMR_OUTPUT_MODE": "2", "BSMR_DENSE_GROUP": "2", "BSMR_DENSE_BLOCKS_PER_WG": "7"},
+    {"BSMR_DENSE_BLOCKS_PER_WG": "1"}, {"BSMR_DENSE_BLOCKS_PER_WG": "5", "BSMR_DENSE_GROUP": "2"},
 ])
 @pytest.mark.parametrize("K", [32, 128, 512])
 def test_plan_knobs(engine, oracle, monkeypatch, knobs, K):
@@ -162,6 +167,28 @@ def test_grouped_format_is_chosen_for_gather_bound_calls(engine, oracle):
         model = oracle.dense_lowp_model(2, rows, K, ro, ci, A, B)
         absdot = oracle.sddmm_f64(rows, K, ro, ci, np.abs(A), np.abs(B))
         assert (np.abs(got - model) <= (K / 32 + 4) * 2.0 ** -23 * absdot).all()
+
+
+def test_unsorted_csr_rows_fall_back_to_direct_scatter(engine, oracle):
+    """CSR rows keep FILE order (reference loader), so column ids inside a row may be in any
+    order; then a block's destinations are not neighbours in P and the plan must use the
+    direct-scatter encoding.  Wide rows (> 255 entries) exercise the item cutting."""
+    rng = np.random.default_rng(3)
+    rows, cols = 96, 900
+    per_row = []
+    for r in range(rows):
+        k = 600 if r % 7 == 0 else int(rng.integers(5, 120))
+        per_row.append(rng.permutation(cols)[:k])                  # unsorted on purpose
+    ro = np.zeros(rows + 1, np.uint32)
+    ro[1:] = np.cumsum([len(c) for c in per_row])
+    ci = np.concatenate(per_row).astype(np.uint32)
+    for K in (64, 128):
+        for delta in (0.0, 0.2):
+            check_case(engine, oracle, rows, cols, ro, ci, K, 0.3, delta, 0)
+    # same pattern with sorted rows: staged encoding, items cut where a row window would overflow
+    ci_sorted = np.concatenate([np.sort(c) for c in per_row]).astype(np.uint32)
+    for K in (64, 128):
+        check_case(engine, oracle, rows, cols, ro, ci_sorted, K, 0.3, 0.0, 0)
 
 
 def test_output_indexing_is_exact(engine, oracle):

@@ -31,17 +31,22 @@ P = torch.zeros(csr.nnz, dtype=torch.float32, device=dev)
 s = torch.cuda.current_stream(dev).cuda_stream
 
 knobs = [{}]
-for h in (1, 2, 4):
-    for bpw in (8, 16, 32):
-        for batch in (4, 8):
-            knobs.append({"BSMR_DENSE_GROUP": str(h), "BSMR_DENSE_BLOCKS_PER_WG": str(bpw), "BSMR_DENSE_BATCH": str(batch)})
+if "--colorder" in sys.argv:
+    for st in (0, 1, 2):
+        for bpw in (16, 32):
+            knobs.append({"BSMR_OUTPUT_MODE": str(st), "BSMR_DENSE_BLOCKS_PER_WG": str(bpw)})
+else:
+    for h in (1, 2, 4):
+        for bpw in (8, 16, 32):
+            for batch in (4, 8):
+                knobs.append({"BSMR_DENSE_GROUP": str(h), "BSMR_DENSE_BLOCKS_PER_WG": str(bpw), "BSMR_DENSE_BATCH": str(batch)})
 if "--sparse" in sys.argv:
     knobs = [{}]
     for lpe in (4, 8, 16):
         for e in (64, 128, 256, 512, 1024):
             knobs.append({"BSMR_SPARSE_LPE": str(lpe), "BSMR_SPARSE_ENTRIES_PER_WG": str(e)})
 ALL = ("BSMR_DENSE_GROUP", "BSMR_DENSE_BLOCKS_PER_WG", "BSMR_DENSE_BATCH", "BSMR_SPARSE_LPE",
-       "BSMR_SPARSE_ENTRIES_PER_WG", "BSMR_FORCE_TILE32")
+       "BSMR_SPARSE_ENTRIES_PER_WG", "BSMR_FORCE_TILE32", "BSMR_COLUMN_ORDER", "BSMR_OUTPUT_MODE")
 for kn in knobs:
     for k in ALL:
         os.environ.pop(k, None)
