@@ -346,16 +346,32 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
     }
 
     // ---- sparse residue -------------------------------------------------------
+    // Entries are independent, so inside a panel they may be visited in any order:
+    // with columnOrder they are sorted by column id and the work items by their first
+    // column, which gives every XCD one column range of B (as for the dense blocks).
     out.entryCol.resize(numSparse);
     out.entryDst.resize(numSparse);
     out.entryRow.resize(numSparse);
-    for (uint64_t i = 0; i < numSparse; ++i) {
+    for (uint64_t i = 0; i < numSparse; ++i)
         if (d->sparse_col_indices[i] >= d->N || d->sparse_values[i] >= d->nnz ||
             d->sparse_relative_rows[i] >= 16)
             return BSMR_ERR_BAD_PLAN;
-        out.entryCol[i] = d->sparse_col_indices[i];
-        out.entryDst[i] = d->sparse_values[i];
-        out.entryRow[i] = (uint8_t)d->sparse_relative_rows[i];
+    {
+        std::vector<uint32_t> perm;
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint32_t s0 = d->sparse_value_offsets[p], s1 = d->sparse_value_offsets[p + 1];
+            perm.resize(s1 - s0);
+            for (uint32_t i = 0; i < s1 - s0; ++i) perm[i] = s0 + i;
+            if (opt.columnOrder)
+                std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) {
+                    return d->sparse_col_indices[a] < d->sparse_col_indices[b];
+                });
+            for (uint32_t i = 0; i < s1 - s0; ++i) {
+                out.entryCol[s0 + i] = d->sparse_col_indices[perm[i]];
+                out.entryDst[s0 + i] = d->sparse_values[perm[i]];
+                out.entryRow[s0 + i] = (uint8_t)d->sparse_relative_rows[perm[i]];
+            }
+        }
     }
     out.numSparseEntries = numSparse;
     if (out.numDenseEntries + numSparse != d->nnz) return BSMR_ERR_BAD_PLAN;
@@ -366,6 +382,10 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
         for (uint32_t s = d->sparse_value_offsets[p]; s < d->sparse_value_offsets[p + 1]; s += perWG)
             out.sparseItems.push_back(
                 SparseItem{p, s, std::min<uint32_t>(perWG, d->sparse_value_offsets[p + 1] - s), 0});
+    if (opt.columnOrder)
+        std::stable_sort(out.sparseItems.begin(), out.sparseItems.end(), [&](const SparseItem& a, const SparseItem& b) {
+            return out.entryCol[a.start] < out.entryCol[b.start];
+        });
     return BSMR_OK;
 }
 
