@@ -12,6 +12,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 be
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/pmc_write.log 2>&1 || exit 1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/pmc_tcc -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/pmc_tcc.log 2>&1 || exit 1
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/pmc_sq.log 2>&1 || echo "sq pass failed"
-rocprofv3 --pmc TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_ta -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/pmc_ta.log 2>&1 || echo "ta pass failed"
+timeout -k 5 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/pmc_sq.log 2>&1 || echo "sq pass failed"
+timeout -k 5 120 rocprofv3 --pmc TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_ta -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/pmc_ta.log 2>&1 || echo "ta pass failed"
 cat $OUT/bench.json
