@@ -94,6 +94,6 @@ def test_cli_contract(engine, tmp_path):
     r = subprocess.run([str(exe), "-f", str(f), "-k", "32", "-a", "0.5", "-d", "0.1"], capture_output=True,
                        text=True, timeout=120)
     # without a GPU the device plan cannot be created, but the record is still printed
-    for key in ("[File : ", "[K : 32]", "[NNZ : 300]", "[bsmr_alpha : 0.5", "[bsmr_delta : 0.1", "[NumRowPanel : ",
+    for key in ("[File : ", "[K : 32]", "[NNZ : 300]", "[bsmr_alpha : 0.50]", "[bsmr_delta : 0.10]", "[NumRowPanel : ",
                 "[bsmr_numDenseBlock : ", "[bsmr_gflops : "):
         assert key in r.stdout, (key, r.stdout, r.stderr)

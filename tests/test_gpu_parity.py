@@ -294,3 +294,96 @@ def test_nips_like_hybrid_k32(engine, oracle):
     """BASELINE configs[0] on the GPU: K=32, alpha=0.3, delta=0.3."""
     rows, cols, ro, ci = synth.nips_like()
     check_case(engine, oracle, rows, cols, ro, ci, 32, 0.3, 0.3, 0)
+
+
+def test_hipgraph_capture_and_replay(engine, oracle):
+    """bsmr_sddmm allocates nothing and never synchronises once bsmr_plan_reserve has run, so a
+    stream capture records it; replaying the graph recomputes P."""
+    rows, cols, ro, ci = synth.random_pattern(300, 400, 12000, seed=77)
+    K = 128
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    pipe = engine.Pipeline(csr, alpha=0.3, delta=0.05, device=0)
+    dev = _dev()
+    A = engine.make_data(rows * K, 5)
+    B = engine.make_data(cols * K, 6)
+    tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    tP = torch.zeros(csr.nnz, dtype=torch.float32, device=dev)
+    assert engine.hip().bsmr_plan_reserve(pipe.plan, K) == engine.OK
+    side = torch.cuda.Stream(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        engine.sddmm(pipe.plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), 0, side.cuda_stream)  # warm-up
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            engine.sddmm(pipe.plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), 0,
+                         torch.cuda.current_stream(dev).cuda_stream)
+    want = oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B)
+    for _ in range(3):
+        tP.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert oracle.check_data(want, tP.cpu().numpy())[0] == 0
+    # new operand values through the same graph (pointers unchanged)
+    A2 = engine.make_data(rows * K, 50)
+    tA.copy_(torch.from_numpy(A2))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert oracle.check_data(oracle.sddmm_cpu(rows, cols, K, ro, ci, A2, B), tP.cpu().numpy())[0] == 0
+
+
+def test_cli_end_to_end_with_validation(engine, tmp_path):
+    """bin/BSMR-sddmm -f m.mtx -k 64 (reference src/main.cu call order) with the in-binary
+    self-check switched on (the reference's `#define VALIDATE`)."""
+    import os
+    import subprocess
+    from pathlib import Path
+    exe = Path(engine.PKG_DIR) / "bin" / "BSMR-sddmm"
+    rows, cols, ro, ci = synth.random_pattern(180, 260, 7000, seed=9, empty_rows=5)
+    f = tmp_path / "m.mtx"
+    synth.write_mtx(f, rows, cols, ro, ci, shuffle_seed=1)
+    env = dict(os.environ, BSMR_VALIDATE="1")
+    r = subprocess.run([str(exe), "-f", str(f), "-k", "64", "-a", "0.3", "-d", "0.1"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "| Pass! Result validates successfully." in r.stdout
+    assert "[checkResults : NO PASS" not in r.stdout and "Error!" not in r.stderr
+    for key in ("[K : 64]", "[NNZ : 7000]", "[bsmr_gflops : ", "[bsmr_sddmm : ", "[mi355x_compute : f16]"):
+        assert key in r.stdout
+    # sweep mode writes one log per (K, alpha, delta): BSMR_k_<K>_a_<alpha>_d_<delta>.log
+    logs = tmp_path / "logs"
+    logs.mkdir()
+    r = subprocess.run([str(exe), "-f", str(f), "-t", "1", "-l", str(logs) + "/"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr
+    names = sorted(p.name for p in logs.iterdir())
+    assert len(names) == 4 * 5 * 7 and "BSMR_k_128_a_0.3_d_0.3.log" in names and "BSMR_k_32_a_0.1_d_0.log" in names
+    assert "BSMR_k_256_a_0.9_d_1.1.log" in names
+    text = (logs / "BSMR_k_128_a_0.3_d_0.3.log").read_text()
+    # two-decimal fixed notation is sticky in the reference's printer (include/Logger.hpp:137)
+    assert "---New data---" in text and "[bsmr_alpha : 0.30]" in text and "[bsmr_delta : 0.30]" in text
+    assert "[mi355x_sddmm_us : " in text
+
+
+def test_medium_scale_properties(engine, oracle):
+    """~2 M entries, 30 k rows: index widths, many workgroups, both paths; checked against the
+    OpenMP oracle (seconds on the GPU box)."""
+    rng = np.random.default_rng(12)
+    rows = cols = 30000
+    deg = np.clip(rng.pareto(1.3, rows) * 30 + 5, 1, 2000).astype(np.int64)
+    deg[rng.random(rows) < 0.05] = 0
+    ro = np.zeros(rows + 1, np.uint32)
+    ro[1:] = np.cumsum(deg)
+    centre = np.repeat(np.arange(rows), deg)
+    ci = (centre + rng.integers(-400, 400, centre.size)) % cols
+    # make (row, col) unique and sorted inside a row
+    key = np.unique(centre * cols + ci)
+    r = key // cols
+    ci = (key % cols).astype(np.uint32)
+    ro = np.zeros(rows + 1, np.int64)
+    np.add.at(ro, r + 1, 1)
+    ro = np.cumsum(ro).astype(np.uint32)
+    K = 64
+    for delta, row_mode in ((0.0, 1), (0.3, 1)):   # identity row order: clustering this size is minutes
+        pipe = check_case(engine, oracle, rows, cols, ro, ci, K, 0.3, delta, 0, row_mode=row_mode)
+        st = pipe.plan_stats()
+        assert st["num_dense_entries"] + st["num_sparse_entries"] == ci.size
