@@ -38,6 +38,7 @@ struct DenseFormat {
     uint8_t* blockMask = nullptr;
     DenseItem* items = nullptr;
     uint32_t numItems = 0;
+    uint32_t maxItemBlocks = 0;
     bool stageInLds = false;       // assemble the row windows in LDS and write them out coalesced
     uint64_t numBlocks = 0, numTiles = 0, unionColumns = 0;
 };
@@ -72,6 +73,7 @@ struct bsmr_plan {
     int sparseLpe = 8;
     bool convertInKernel = false;  // dense part so small that the full operand conversion pass does not pay
     int denseBatch = 0;            // blocks per LDS batch at K = 128 (0 = default)
+    bool useStream = true;         // streaming kernel for ungrouped plans (BSMR_DENSE_STREAM=0 disables)
 };
 
 namespace {
@@ -140,6 +142,8 @@ void freePlanDevice(bsmr_plan* p) {
 int uploadDense(DenseFormat& f, const bsmr::PackedPlan& pk, uint64_t& bytes) {
     f.H = pk.H;
     f.numItems = (uint32_t)pk.denseItems.size();
+    f.maxItemBlocks = 0;
+    for (const DenseItem& it : pk.denseItems) f.maxItemBlocks = std::max(f.maxItemBlocks, it.count);
     f.numBlocks = pk.numBlocks;
     f.numTiles = pk.numTiles;
     f.unionColumns = pk.unionColumns;
@@ -196,6 +200,31 @@ int launchGroupsT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
     return BSMR_OK;
 }
 
+// streaming form for ungrouped plans whose items hold <= 32 blocks (8 per wave)
+template <int KS, int MODE, typename TileT>
+int launchStreamT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, const TileT* tiles, float* P,
+                  hipStream_t s) {
+    auto kernel = bsmr::denseStream<KS, MODE, TileT>;
+    const size_t lds = (size_t)bsmr::kWavesPerWG * 2 * 1024u * KS;  // wave-private double buffer
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        BSMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(f.numItems), dim3(bsmr::kThreads), lds, s, A16, B16, f.groupRows, f.rowBase,
+                       f.blockCols, tiles, f.items, P);
+    BSMR_HIP(hipGetLastError());
+    return BSMR_OK;
+}
+
+template <int KS, int MODE>
+int launchStream(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+    if (f.tiles8) return launchStreamT<KS, MODE, uint8_t>(f, A16, B16, f.tiles8, P, s);
+    return f.tiles16 ? launchStreamT<KS, MODE, uint16_t>(f, A16, B16, f.tiles16, P, s)
+                     : launchStreamT<KS, MODE, uint32_t>(f, A16, B16, f.tiles32, P, s);
+}
+
 template <int KS, int H, int NB, int MODE>
 int launchGroups(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
     if (f.tiles8)
@@ -219,6 +248,16 @@ int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uin
                   hipStream_t s) {
     const DenseFormat& f = chooseFormat(p, K);
     if (f.numItems == 0) return BSMR_OK;
+    if (f.H == 1 && f.maxItemBlocks <= 32 && !f.stageInLds && p->useStream) {
+        switch (K) {
+        case 32: return launchStream<1, MODE>(f, A16, B16, P, s);
+        case 64: return launchStream<2, MODE>(f, A16, B16, P, s);
+        case 128: return launchStream<4, MODE>(f, A16, B16, P, s);
+        case 256: return launchStream<8, MODE>(f, A16, B16, P, s);
+        case 512: return launchStream<16, MODE>(f, A16, B16, P, s);
+        default: break;
+        }
+    }
     switch (K) {
     case 32: return launchGroupsH<1, 16, MODE>(f, A16, B16, P, s);
     case 64: return launchGroupsH<2, 8, MODE>(f, A16, B16, P, s);
@@ -503,6 +542,7 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         p->sparseLpe = envInt("BSMR_SPARSE_LPE", 8);
         if (p->sparseLpe != 4 && p->sparseLpe != 8 && p->sparseLpe != 16) p->sparseLpe = 8;
         p->denseBatch = envInt("BSMR_DENSE_BATCH", 0);
+        p->useStream = envInt("BSMR_DENSE_STREAM", 1) != 0;
         // full conversion moves 6 bytes per operand element; the in-kernel path reads each
         // gathered element as fp32 (4 B, A re-read per block) from a slower kernel
         const int cvt = envInt("BSMR_CONVERT_IN_KERNEL", -1);

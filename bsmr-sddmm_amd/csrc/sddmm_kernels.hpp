@@ -198,6 +198,7 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     constexpr uint32_t MINE = (NBW + NSUB - 1) / NSUB;  // blocks of a batch one wave multiplies
     constexpr uint32_t CREG = (NBW + 3) / 4;         // registers holding the batch's column ids
     constexpr uint32_t DMAS = (NBW * KS + kWavesPerWG - 1) / kWavesPerWG;  // DMA instructions per wave and batch
+    constexpr bool PRIVATE = H == 1 && NBW % kWavesPerWG == 0;  // wave-private B blocks, no barriers
     typedef typename TileLoad<TileT>::raw TileRaw;
     static_assert(NBW <= 16 && (NBW & (NBW - 1)) == 0, "NBW must be a power of two <= 16");
 
@@ -244,9 +245,19 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
         uint8_t* base = lds + buf * (NBW * blkBytes);
 #pragma unroll
         for (uint32_t d = 0; d < DMAS; ++d) {
-            const uint32_t i = d * kWavesPerWG + wave;
-            if (NBW * KS % kWavesPerWG != 0 && i >= NBW * KS) break;
-            const uint32_t n = i / KS, j = i % KS;
+            // H == 1: a wave gathers exactly the blocks it multiplies (n = wave, wave+4, ...),
+            // so the waves never read each other's LDS and need no barrier.  H > 1: the
+            // batch is shared by the panels, instructions are dealt round-robin.
+            uint32_t n, j;
+            if constexpr (PRIVATE) {
+                n = wave + kWavesPerWG * (d / KS);
+                j = d % KS;
+            } else {
+                const uint32_t i = d * kWavesPerWG + wave;
+                if (NBW * KS % kWavesPerWG != 0 && i >= NBW * KS) break;
+                n = i / KS;
+                j = i % KS;
+            }
             const uint32_t f = 64u * j + lane;
             const uint32_t col = f / PC, t = f % PC;
             uint32_t cid = 0;
@@ -291,7 +302,8 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
         const uint32_t b0 = item.first + it * NBW;
         // batch `it` has landed (every wave drains its own DMA, then all meet); the
         // other buffer is free because every wave finished batch it-1 before arriving.
-        __syncthreads();
+        if constexpr (PRIVATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __syncthreads();
         if constexpr (!STAGED) {
 #pragma unroll
             for (uint32_t m = 0; m < MINE; ++m)
@@ -354,6 +366,127 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
         for (uint32_t m = 0; m < MINE; ++m)
             if (pendBits & (1u << m)) scatterTile<TileT>(pendAcc[m], pendTile[m], rowBase, P);
     }
+}
+
+// ---------------------------------------------------------------------------
+// dense kernel for ungrouped plans (H = 1), K = 32*KS: the streaming form.
+//
+// Ablation of denseGroups on the nips-like matrix showed that more than half of
+// its time is a fixed skeleton: every batch ends in `s_waitcnt vmcnt(0)`, which
+// waits for that iteration's metadata loads and for the scattered stores (gfx950
+// has ONE counter for loads and stores), i.e. one full memory round trip per batch.
+// Here a wave owns up to MAXB blocks of the item (block wave + 4m) and
+//   * loads ALL of its metadata (column ids, destination tiles, A fragments) in the
+//     prologue and drains it before the first gather is issued,
+//   * then runs a loop whose only vector-memory operations are the LDS-DMA gathers
+//     of a wave-private double buffer, so the wait for block m is the counted
+//     `vmcnt(KS)` (block m+1 stays in flight) - no barriers, no round trip per block,
+//   * keeps the accumulators of all its blocks in registers and scatters them after
+//     the loop, when nothing has to wait for the stores.
+// ---------------------------------------------------------------------------
+template <int KS, int MODE, typename TileT, int MAXB = 8>
+__global__ void __launch_bounds__(kThreads)
+denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
+            const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ rowBaseTable,
+            const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
+            const DenseItem* __restrict__ items, float* __restrict__ P) {
+    constexpr uint32_t K = 32u * KS;
+    constexpr uint32_t PC = 4u * KS;
+    constexpr uint32_t SW = PC - 1u < 15u ? PC - 1u : 15u;
+    constexpr uint32_t rowBytes = 2u * K;
+    constexpr uint32_t blkBytes = 16u * rowBytes;
+    constexpr bool WINDOWED = sizeof(TileT) == 1;
+    constexpr uint32_t CREG = (MAXB + 3) / 4;
+    typedef typename TileLoad<TileT>::raw TileRaw;
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [4 waves][2][blkBytes]
+    const uint32_t itemId = xcdContiguous(blockIdx.x, gridDim.x);
+    const DenseItem item = items[itemId];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t r = lane & 15u, g = lane >> 4;
+    uint8_t* myLds = lds + wave * (2u * blkBytes);
+    // blocks of this wave: item.first + wave + 4m, m < myCount
+    const uint32_t myCount = item.count > wave ? min((item.count - wave + 3u) >> 2, (uint32_t)MAXB) : 0u;
+    if (myCount == 0) return;
+    const uint32_t myFirst = item.first + wave;
+
+    // ---- prologue: every ordinary load of the wave ----
+    uint32_t cols[CREG];   // lane l, register q: column (l & 15) of my block 4q + (l >> 4)
+#pragma unroll
+    for (uint32_t q = 0; q < CREG; ++q)
+        cols[q] = blockCols[(size_t)(myFirst + 4u * min(4u * q + g, myCount - 1u)) * 16u + r];
+    TileRaw tile[MAXB];
+#pragma unroll
+    for (uint32_t m = 0; m < (uint32_t)MAXB; ++m)
+        if (m < myCount) tile[m] = loadTile<TileT>(tiles, (size_t)(myFirst + 4u * m), lane);
+    const uint32_t rowSlot = item.group * 16u;
+    uint32_t rowBase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        rowBase[i] = WINDOWED ? rowBaseTable[(size_t)itemId * 16u + 4u * g + i] : rowBaseTable[rowSlot + 4u * g + i];
+    u32x4 a[KS];
+    {
+        const uint16_t* aRow = A16 + (size_t)groupRows[rowSlot + r] * K + g * 8u;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const u32x4*>(aRow + s * 32);
+    }
+    // Drain them now and mark them consumed: while an LDS-DMA is in flight the compiler
+    // would otherwise put a full vmcnt(0) in front of the first use of any of these.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[s]));
+#pragma unroll
+    for (uint32_t q = 0; q < CREG; ++q) asm volatile("" : "+v"(cols[q]));
+#pragma unroll
+    for (uint32_t m = 0; m < (uint32_t)MAXB; ++m) asm volatile("" : "+v"(tile[m]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(rowBase[i]));
+
+    auto gather = [&](uint32_t m) {  // my block m -> slot m & 1
+        uint8_t* dst = myLds + (m & 1u) * blkBytes;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const uint32_t f = 64u * j + lane;
+            const uint32_t col = f / PC, t = f % PC;
+            const uint32_t cid = __shfl(cols[m >> 2], ((m & 3u) << 4) + col);
+            const uint16_t* src = B16 + (size_t)cid * K + ((t ^ (col & SW)) << 3);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)src,
+                (__attribute__((address_space(3))) void*)(dst + j * 1024u), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[MAXB];
+    gather(0);
+#pragma unroll
+    for (uint32_t m = 0; m < (uint32_t)MAXB; ++m) {
+        if (m >= myCount) break;  // wave-uniform
+        if (m + 1 < myCount) {
+            gather(m + 1);
+            // KS gathers (block m+1) may stay in flight; everything older has landed
+            if constexpr (KS == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if constexpr (KS == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if constexpr (KS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (KS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const uint8_t* bCol = myLds + (m & 1u) * blkBytes + r * rowBytes;
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const u32x4 bv = *reinterpret_cast<const u32x4*>(bCol + (((4u * s + g) ^ (r & SW)) << 4));
+            c = mfma16<MODE>(a[s], bv, c);
+        }
+        acc[m] = c;
+        // slot m & 1 is rewritten by gather(m + 2): its reads must have returned
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (uint32_t m = 0; m < (uint32_t)MAXB; ++m)
+        if (m < myCount) scatterTile<TileT>(acc[m], tile[m], rowBase, P);
 }
 
 // ---------------------------------------------------------------------------
