@@ -107,12 +107,40 @@ inline void unionColumns(const bsmr_rphm_desc* d, uint32_t p0, uint32_t h, uint3
             out[it->second].slot[k] = (int32_t)t;
         }
     }
-    if (byColumnId)
-        std::sort(out.begin(), out.end(), [](const ColumnUse& a, const ColumnUse& b) { return a.col < b.col; });
-    else
+    if (!byColumnId) {
         std::sort(out.begin(), out.end(), [](const ColumnUse& a, const ColumnUse& b) {
             return a.count != b.count ? a.count > b.count : a.col < b.col;
         });
+        return;
+    }
+    std::sort(out.begin(), out.end(), [](const ColumnUse& a, const ColumnUse& b) { return a.col < b.col; });
+    if (h == 1) return;
+    // Grouped plans: a block of 16 union columns costs one tile per panel that has an
+    // entry in it.  Mixing columns shared by several panels with columns only one
+    // panel uses would make almost every (block, panel) tile non-empty, so the columns
+    // are partitioned: first the columns at least two panels share (column-id order),
+    // then the single-panel columns, dealt 16 at a time round-robin over the panels so
+    // that the four waves (one per panel) of a batch of blocks all have a tile to do.
+    std::vector<ColumnUse> shared, single[kMaxGroup];
+    for (const ColumnUse& c : out) {
+        int panels = 0, only = 0;
+        for (uint32_t k = 0; k < h; ++k)
+            if (c.slot[k] >= 0) { ++panels; only = (int)k; }
+        if (panels >= 2) shared.push_back(c);
+        else single[only].push_back(c);
+    }
+    out.swap(shared);
+    size_t cursor[kMaxGroup] = {0, 0, 0, 0};
+    for (bool any = true; any;) {
+        any = false;
+        for (uint32_t k = 0; k < h; ++k) {
+            const size_t n = std::min<size_t>(16, single[k].size() - cursor[k]);
+            if (!n) continue;
+            out.insert(out.end(), single[k].begin() + cursor[k], single[k].begin() + cursor[k] + n);
+            cursor[k] += n;
+            any = true;
+        }
+    }
 }
 
 }  // namespace detail
