@@ -205,7 +205,7 @@ template <int KS, int MODE, typename TileT>
 int launchStreamT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, const TileT* tiles, float* P,
                   hipStream_t s) {
     auto kernel = bsmr::denseStream<KS, MODE, TileT>;
-    const size_t lds = (size_t)bsmr::kWavesPerWG * 2 * 1024u * KS;  // wave-private double buffer
+    const size_t lds = (size_t)bsmr::kWavesPerWG * bsmr::streamSlots(KS) * 1024u * KS;  // wave-private ring
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         BSMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),

@@ -384,6 +384,11 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
 //   * keeps the accumulators of all its blocks in registers and scatters them after
 //     the loop, when nothing has to wait for the stores.
 // ---------------------------------------------------------------------------
+// block images in a wave's gather ring.  Three images (two gathers in flight) measured the
+// same as two on MI355X (10.0 vs 10.1 us, nips-like K = 128): the loop is bound by gather
+// throughput, not by the latency of one gather, so the smaller footprint is kept.
+constexpr uint32_t streamSlots(int /*KS*/) { return 2u; }
+
 template <int KS, int MODE, typename TileT, int MAXB = 8>
 __global__ void __launch_bounds__(kThreads)
 denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
@@ -397,15 +402,16 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     constexpr uint32_t blkBytes = 16u * rowBytes;
     constexpr bool WINDOWED = sizeof(TileT) == 1;
     constexpr uint32_t CREG = (MAXB + 3) / 4;
+    constexpr uint32_t SLOTS = streamSlots(KS);
     typedef typename TileLoad<TileT>::raw TileRaw;
 
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [4 waves][2][blkBytes]
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [4 waves][SLOTS][blkBytes]
     const uint32_t itemId = xcdContiguous(blockIdx.x, gridDim.x);
     const DenseItem item = items[itemId];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t r = lane & 15u, g = lane >> 4;
-    uint8_t* myLds = lds + wave * (2u * blkBytes);
+    uint8_t* myLds = lds + wave * (SLOTS * blkBytes);
     // blocks of this wave: item.first + wave + 4m, m < myCount
     const uint32_t myCount = item.count > wave ? min((item.count - wave + 3u) >> 2, (uint32_t)MAXB) : 0u;
     if (myCount == 0) return;
@@ -443,8 +449,10 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
 #pragma unroll
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(rowBase[i]));
 
-    auto gather = [&](uint32_t m) {  // my block m -> slot m & 1
-        uint8_t* dst = myLds + (m & 1u) * blkBytes;
+    // ring of SLOTS block images per wave: SLOTS-1 gathers stay in flight (a gather takes
+    // ~1200 cycles under load, a block's MFMAs ~400: measured with in-kernel stamps)
+    auto gather = [&](uint32_t m) {  // my block m -> slot m % SLOTS
+        uint8_t* dst = myLds + (m % SLOTS) * blkBytes;
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
             const uint32_t f = 64u * j + lane;
@@ -456,24 +464,30 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
                 (__attribute__((address_space(3))) void*)(dst + j * 1024u), 16, 0, 0);
         }
     };
+    auto waitInFlight = [&](uint32_t blocks) {  // all but the youngest `blocks` gathers have landed
+        if (blocks == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (blocks * KS == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (blocks * KS == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (blocks * KS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (blocks * KS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (blocks * KS == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    };
 
     f32x4 acc[MAXB];
-    gather(0);
+#pragma unroll
+    for (uint32_t m = 0; m + 1 < SLOTS; ++m)
+        if (m < myCount) gather(m);
 #pragma unroll
     for (uint32_t m = 0; m < (uint32_t)MAXB; ++m) {
         if (m >= myCount) break;  // wave-uniform
-        if (m + 1 < myCount) {
-            gather(m + 1);
-            // KS gathers (block m+1) may stay in flight; everything older has landed
-            if constexpr (KS == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else if constexpr (KS == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if constexpr (KS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if constexpr (KS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        const uint8_t* bCol = myLds + (m & 1u) * blkBytes + r * rowBytes;
+        // slot (m + SLOTS - 1) % SLOTS held block m-1, whose reads returned before its MFMAs
+        if (m + SLOTS - 1 < myCount) gather(m + SLOTS - 1);
+        const uint32_t younger = min(myCount - 1u - m, SLOTS - 1u);  // gathers issued after block m's
+        if (younger == 0) waitInFlight(0);
+        else if (younger == 1) waitInFlight(1);
+        else waitInFlight(2);
+        const uint8_t* bCol = myLds + (m % SLOTS) * blkBytes + r * rowBytes;
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -481,7 +495,6 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
             c = mfma16<MODE>(a[s], bv, c);
         }
         acc[m] = c;
-        // slot m & 1 is rewritten by gather(m + 2): its reads must have returned
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 #pragma unroll

@@ -53,6 +53,14 @@ class PlanStats(C.Structure):
                 ("grouped_union_columns", C.c_uint64)]
 
 
+class ReorderingReport(C.Structure):
+    _fields_ = [("original_num_dense_blocks", C.c_int32), ("original_average_density", C.c_float),
+                ("num_dense_blocks", C.c_int32), ("average_density", C.c_float),
+                ("num_dense_thread_blocks", C.c_int32), ("num_sparse_thread_blocks", C.c_int32),
+                ("num_dense_data", C.c_int32), ("num_sparse_data", C.c_int32),
+                ("max_dense_blocks_per_panel", C.c_uint32), ("max_sparse_blocks_per_panel", C.c_uint32)]
+
+
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("convert_ms", C.c_float), ("dense_ms", C.c_float),
                 ("sparse_ms", C.c_float)]
@@ -113,6 +121,7 @@ HOST_SYMBOLS = {
     "bsmr_pipeline_col_reordering_ms": (C.c_float, [C.c_void_p]),
     "bsmr_pipeline_rphm_ms": (C.c_float, [C.c_void_p]),
     "bsmr_pipeline_check": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float]),
+    "bsmr_pipeline_evaluate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "bsmr_pipeline_plan": (C.c_void_p, [C.c_void_p]),
     "bsmr_pipeline_plan_status": (C.c_int, [C.c_void_p]),
     "bsmr_host_sddmm_cpu": (None, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -284,6 +293,13 @@ class Pipeline:
 
     def check(self) -> bool:
         return bool(host().bsmr_pipeline_check(self._h, self.csr.handle, self.delta))
+
+    def evaluate(self) -> dict:
+        """evaluationReordering: the statistics the reference logs for this (alpha, delta)."""
+        rep = ReorderingReport()
+        _check(host().bsmr_pipeline_evaluate(self._h, self.csr.handle, self.delta, C.byref(rep)),
+               "bsmr_pipeline_evaluate")
+        return {name: getattr(rep, name) for name, _ in ReorderingReport._fields_}
 
     @property
     def plan(self):

@@ -154,3 +154,77 @@ def write_mtx(path, rows, cols, ro, ci, shuffle_seed=None, values=None):
         for i in order:
             v = 1 if values is None else values[i]
             f.write(f"{r[i] + 1} {ci[i] + 1} {v}\n")
+
+
+# ---------------------------------------------------------------------------
+# SuiteSparse matrices whose pattern is defined by a formula.  The collection stores
+# symmetric matrices as their lower triangle in column-major order, and the reference's
+# loader does not expand `symmetric` files (src/Matrix.cpp:398-480), so what the
+# pipeline sees - and what these return - is the lower triangle as a CSR with ascending
+# columns.  The `NNZ` the reference logged for each of them equals these counts
+# (tests/golden/reference_logs.json).
+# ---------------------------------------------------------------------------
+def _lower_csr(n: int, r: np.ndarray, c: np.ndarray):
+    keep = r >= c
+    key = np.unique(r[keep].astype(np.int64) * n + c[keep].astype(np.int64))
+    r, c = key // n, key % n
+    ro = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(ro, r + 1, 1)
+    return n, n, np.cumsum(ro).astype(np.uint32), c.astype(np.uint32)
+
+
+def trefethen_pattern(n=20000):
+    """JGD_Trefethen/Trefethen_<n>: primes on the diagonal, ones where |i - j| is a power
+    of two.  Trefethen_20000b (the same without the first row and column) has the pattern
+    of n = 19999."""
+    r, c = [np.arange(n)], [np.arange(n)]
+    d = 1
+    while d < n:
+        r.append(np.arange(d, n))
+        c.append(np.arange(d, n) - d)
+        d *= 2
+    return _lower_csr(n, np.concatenate(r), np.concatenate(c))
+
+
+def mycielskian_pattern(k=14):
+    """Mycielski/mycielskian<k>: M2 is one edge; M(j+1) = [M M 0; M 0 1; 0 1' 0] on
+    2n+1 vertices (copies n..2n-1, apex 2n)."""
+    e = np.array([[1, 0]], dtype=np.int64)
+    n = 2
+    for _ in range(k - 2):
+        a, b = e[:, 0], e[:, 1]
+        apex = np.stack([np.full(n, 2 * n), np.arange(n, 2 * n)], 1)
+        e = np.concatenate([e, np.stack([a + n, b], 1), np.stack([b + n, a], 1), apex])
+        n = 2 * n + 1
+    return _lower_csr(n, e[:, 0], e[:, 1])
+
+
+def wathen_pattern(nx=100, ny=100):
+    """gallery('wathen', nx, ny): every pair of the 8 nodes of a serendipity element is
+    coupled; node numbering of Higham's wathen.m.  GHS_psdef/wathen100 is (100, 100),
+    wathen120 is (nx, ny) = (100, 120) - the other orientation has the same size and nnz
+    but not the statistics the reference logged."""
+    n = 3 * nx * ny + 2 * nx + 2 * ny + 1
+    j, i = np.meshgrid(np.arange(1, ny + 1), np.arange(1, nx + 1), indexing="ij")
+    j, i = j.ravel().astype(np.int64), i.ravel().astype(np.int64)
+    nn = np.zeros((8, i.size), dtype=np.int64)
+    nn[0] = 3 * j * nx + 2 * i + 2 * j + 1
+    nn[1] = nn[0] - 1
+    nn[2] = nn[1] - 1
+    nn[3] = (3 * j - 1) * nx + 2 * j + i - 1
+    nn[4] = 3 * (j - 1) * nx + 2 * i + 2 * j - 3
+    nn[5] = nn[4] + 1
+    nn[6] = nn[5] + 1
+    nn[7] = nn[3] + 1
+    nn -= 1
+    return _lower_csr(n, np.repeat(nn, 8, axis=0).ravel(), np.tile(nn, (8, 1)).ravel())
+
+
+def write_mtx_columnwise(path, rows, cols, ro, ci, header="%%MatrixMarket matrix coordinate pattern symmetric"):
+    """The file layout of the collection: entries column by column, rows ascending."""
+    r = np.repeat(np.arange(rows), np.diff(ro.astype(np.int64)))
+    order = np.lexsort((r, ci))
+    with open(path, "w") as f:
+        f.write(header + "\n")
+        f.write(f"{rows} {cols} {ci.size}\n")
+        np.savetxt(f, np.stack([r[order] + 1, ci[order].astype(np.int64) + 1], 1), fmt="%d")

@@ -156,6 +156,26 @@ int bsmr_pipeline_check(const bsmr_pipeline* p, const bsmr_csr* m, float delta) 
     return guarded([&]() -> int { return check_rphm(m->m, p->bsmr, *p->rphm, delta) ? 1 : 0; }, 0);
 }
 
+int bsmr_pipeline_evaluate(const bsmr_pipeline* p, const bsmr_csr* m, float delta, bsmr_reordering_report* out) {
+    if (!p || !m || !out || !p->rphm) return BSMR_ERR_INVALID_ARG;
+    return guarded([&]() -> int {
+        Logger logger;
+        logger.delta_ = delta;
+        evaluationReordering(m->m, p->bsmr, logger);
+        out->original_num_dense_blocks = logger.originalNumDenseBlock_;
+        out->original_average_density = logger.originalAverageDensity_;
+        out->num_dense_blocks = logger.numDenseBlock_;
+        out->average_density = logger.averageDensity_;
+        out->num_dense_thread_blocks = logger.numDenseThreadBlocks_;
+        out->num_sparse_thread_blocks = logger.numSparseThreadBlocks_;
+        out->num_dense_data = logger.numDenseData_;
+        out->num_sparse_data = logger.numSparseData_;
+        out->max_dense_blocks_per_panel = p->rphm->maxNumDenseColBlocksInRowPanel();
+        out->max_sparse_blocks_per_panel = p->rphm->maxNumSparseColBlocksInRowPanel();
+        return BSMR_OK;
+    }, BSMR_ERR_OOM);
+}
+
 bsmr_plan* bsmr_pipeline_plan(const bsmr_pipeline* p) { return p && p->rphm ? p->rphm->plan() : nullptr; }
 int bsmr_pipeline_plan_status(const bsmr_pipeline* p) {
     return p && p->rphm ? p->rphm->planStatus() : BSMR_ERR_INVALID_ARG;

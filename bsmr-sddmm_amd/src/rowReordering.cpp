@@ -12,16 +12,24 @@
 // implementation does.  It never materialises the dense rows x bins table
 // (5.7 GB for a reddit-sized matrix): every row keeps a sorted (bin, count)
 // list, and an inverted bin -> rows index restricts each cluster's scan to the
-// rows that share a bin with the running representative.  A row that shares no
-// bin has similarity 0 and is rejected for every alpha >= 0, so skipping it does
-// not change the outcome.
+// rows that share a bin with the running representative.
 //
-// Numerics: sums of squares are integers (64-bit here; the reference's 32-bit
-// sums overflow on very large clusters); norms, quotients and the min/max sums
-// are fp32, accumulated over the row's bins in ascending order plus one exact
-// integer remainder term (see similarity()).  The reference sums all bins with a
-// block-wide tree, so rows whose similarity sits within rounding of alpha may
-// fall on the other side; any permutation is valid for SDDMM parity.
+// Numerics - the similarity is evaluated exactly as the reference's block
+// executes it, which is what makes cluster counts and dense-block statistics equal
+// the reference's published logs (tests/test_reference_logs.py):
+//   * a block of T = clusterThreads(numBins) threads (:912-922); thread t owns bins
+//     t, t+T, ... and accumulates them in that order in fp32;
+//   * the block-wide sum (include/cudaUtil.cuh:14-45) adds the 32 lanes of a warp in
+//     a balanced tree and then folds the warps with `for (s = T/64; s; s >>= 1)
+//     v[w] += v[w+s]`: when T/32 is not a power of two some warps are never read, so
+//     their bins take no part in the sums of squares, the min-sum or the max-sum
+//     (BlockSum::live marks the bins that count);
+//   * sums of squares are 32-bit unsigned with wrap-around, norms are sqrtf of their
+//     float conversion, quotients are IEEE fp32 divisions.
+// The fixed shape of that sum is kept as an explicit binary tree: the values of the
+// representative alone are cached per node, and one (representative, row) pair only
+// recomputes the leaves the row touches and their ancestors - O(|row| log T) per pair
+// instead of O(numBins), with bit-identical results.
 
 #include <algorithm>
 #include <chrono>
@@ -32,8 +40,12 @@
 #include <queue>
 #include <vector>
 
+#include <omp.h>
+
 #include "BSMR.hpp"
 #include "bsmr_hip.h"
+
+constexpr UIN WARP_SIZE_NV = 32;  // the reference's block reduction is defined on 32-lane warps
 
 namespace {
 
@@ -42,6 +54,53 @@ inline float msSince(const Clock::time_point& t0) {
     return std::chrono::duration<float, std::milli>(Clock::now() - t0).count();
 }
 
+// threads of the reference's clustering block (src/rowReordering.cu:912-922)
+UIN clusterThreads(const size_t numBins) {
+    if (numBins < 32) return 32;
+    const UIN candidate =
+        WARP_SIZE_NV * static_cast<UIN>(std::ceil(static_cast<float>(numBins / 4) / static_cast<float>(WARP_SIZE_NV)));
+    return std::min<UIN>(1024, std::max<UIN>(32, candidate));
+}
+
+// The reference's block-wide sum as a binary tree over the T per-thread partials.
+// Nodes 0..T-1 are the leaves; children always have smaller ids than their parent.
+struct BlockSum {
+    UIN threads = 0;
+    std::vector<int> left, right, parent;
+    std::vector<uint8_t> live;  // node contributes to the root
+    int root = 0;
+
+    explicit BlockSum(UIN T) : threads(T) {
+        const UIN warps = T / WARP_SIZE_NV;
+        left.assign(T, -1);
+        right.assign(T, -1);
+        auto join = [&](int a, int b) {
+            left.push_back(a);
+            right.push_back(b);
+            return static_cast<int>(left.size()) - 1;
+        };
+        std::vector<int> slot(warps);
+        for (UIN w = 0; w < warps; ++w) {
+            int lane[WARP_SIZE_NV];
+            for (UIN l = 0; l < WARP_SIZE_NV; ++l) lane[l] = static_cast<int>(WARP_SIZE_NV * w + l);
+            for (UIN step = 1; step < WARP_SIZE_NV; step <<= 1)  // shuffle-xor butterfly, lane 0
+                for (UIN l = 0; l < WARP_SIZE_NV; l += 2 * step) lane[l] = join(lane[l], lane[l + step]);
+            slot[w] = lane[0];
+        }
+        for (UIN s = T / (2 * WARP_SIZE_NV); s >= 1; s >>= 1)  // include/cudaUtil.cuh:37-43
+            for (UIN w = 0; w < s; ++w) slot[w] = join(slot[w], slot[w + s]);
+        root = slot[0];
+        parent.assign(left.size(), -1);
+        for (size_t n = T; n < left.size(); ++n) parent[left[n]] = parent[right[n]] = static_cast<int>(n);
+        live.assign(left.size(), 0);
+        live[root] = 1;
+        for (int n = root; n >= static_cast<int>(T); --n)
+            if (live[n]) live[left[n]] = live[right[n]] = 1;
+    }
+    size_t nodes() const { return left.size(); }
+    bool binCounts(UIN bin) const { return live[bin % threads] != 0; }
+};
+
 struct BinCount {
     UIN bin;
     UIN count;
@@ -49,15 +108,15 @@ struct BinCount {
 
 // Per-row sparse histogram in CSR-like storage.
 struct RowEncodings {
-    std::vector<size_t> offsets;  // rows + 1
-    std::vector<BinCount> items;  // sorted by bin inside a row
-    std::vector<UIN> dispersion;  // 0 for empty rows
-    std::vector<uint64_t> squares; // sum of count^2 per row
+    std::vector<size_t> offsets;   // rows + 1
+    std::vector<BinCount> items;   // sorted by bin inside a row
+    std::vector<UIN> dispersion;   // 0 for empty rows
+    std::vector<uint32_t> squares; // sum of count^2 over the bins that count, modulo 2^32
     const BinCount* begin(UIN row) const { return items.data() + offsets[row]; }
     const BinCount* end(UIN row) const { return items.data() + offsets[row + 1]; }
 };
 
-RowEncodings buildEncodings(const sparseMatrix::CSR<float>& m, const UIN binWidth) {
+RowEncodings buildEncodings(const sparseMatrix::CSR<float>& m, const UIN binWidth, const BlockSum& sum) {
     const UIN rows = m.row();
     RowEncodings enc;
     enc.offsets.assign(static_cast<size_t>(rows) + 1, 0);
@@ -92,14 +151,16 @@ RowEncodings buildEncodings(const sparseMatrix::CSR<float>& m, const UIN binWidt
             for (UIN i = b; i < e; ++i) bins.push_back(m.colIndices()[i] / binWidth);
             std::sort(bins.begin(), bins.end());
             BinCount* out = enc.items.data() + enc.offsets[r];
-            uint64_t slack = 0, sq = 0;
+            uint64_t slack = 0;
+            uint32_t sq = 0;
             size_t n = 0;
             for (size_t i = 0; i < bins.size();) {
                 size_t j = i;
                 while (j < bins.size() && bins[j] == bins[i]) ++j;
-                out[n++] = BinCount{bins[i], static_cast<UIN>(j - i)};
-                slack += binWidth - static_cast<UIN>(j - i);
-                sq += static_cast<uint64_t>(j - i) * (j - i);
+                const UIN c = static_cast<UIN>(j - i);
+                out[n++] = BinCount{bins[i], c};
+                slack += binWidth - c;
+                if (sum.binCounts(bins[i])) sq += c * c;
                 i = j;
             }
             // sum over touched bins of (width - count)  +  nnz * #touched bins
@@ -110,58 +171,111 @@ RowEncodings buildEncodings(const sparseMatrix::CSR<float>& m, const UIN binWidt
     return enc;
 }
 
-// Running representative of one cluster: dense counts + list of touched bins.
+// Running representative of one cluster: dense counts, the touched bins, and the
+// block-sum tree of its own normalised counts (what every pair starts from).
 struct Representative {
-    std::vector<UIN> count;     // numBins, zero outside `bins`
-    std::vector<UIN> bins;      // touched bins, in order of first touch
-    uint64_t sumSquares = 0;    // sum of count^2
-    uint64_t total = 0;         // sum of count
+    const BlockSum& sum;
+    size_t numBins;
+    std::vector<UIN> count;       // numBins, zero outside `bins`
+    std::vector<UIN> bins;        // touched bins, in order of first touch
+    uint32_t sumSquares = 0;      // over the bins that count, modulo 2^32 (UIN accumulator of the reference)
+    float norm = 0.0f;            // sqrtf(float(sumSquares))
+    std::vector<float> maxTree;   // per node: block sum of count/norm over the representative alone
 
-    explicit Representative(size_t numBins) : count(numBins, 0) {}
+    Representative(const BlockSum& s, size_t nb) : sum(s), numBins(nb), count(nb, 0), maxTree(s.nodes(), 0.0f) {}
 
     void clear() {
         for (const UIN b : bins) count[b] = 0;
         bins.clear();
         sumSquares = 0;
-        total = 0;
     }
 
-    // rep += row; returns (via newBins) the bins that were empty before.
+    // rep += row; returns (via newBins) the bins that count and were empty before.
     void add(const BinCount* rb, const BinCount* re, std::vector<UIN>& newBins) {
         newBins.clear();
         for (const BinCount* it = rb; it != re; ++it) {
-            const uint64_t old = count[it->bin];
-            if (old == 0) newBins.push_back(it->bin);
-            sumSquares += 2 * old * it->count + static_cast<uint64_t>(it->count) * it->count;
-            total += it->count;
+            const UIN old = count[it->bin];
+            if (old == 0) bins.push_back(it->bin);
+            if (sum.binCounts(it->bin)) {
+                if (old == 0) newBins.push_back(it->bin);
+                sumSquares += 2u * old * it->count + it->count * it->count;
+            }
             count[it->bin] += it->count;
         }
-        bins.insert(bins.end(), newBins.begin(), newBins.end());
+        rebuild();
+    }
+
+    void rebuild() {
+        norm = std::sqrt(static_cast<float>(sumSquares));
+        const UIN T = sum.threads;
+        if (sumSquares == 0) return;  // similarity never reaches the sums
+        for (UIN t = 0; t < T; ++t) {
+            float acc = 0.0f;
+            if (sum.live[t])
+                for (size_t b = t; b < numBins; b += T) acc = acc + static_cast<float>(count[b]) / norm;
+            maxTree[t] = acc;
+        }
+        for (size_t n = T; n < sum.nodes(); ++n) maxTree[n] = maxTree[sum.left[n]] + maxTree[sum.right[n]];
     }
 };
 
-// Normalised weighted Jaccard similarity of the representative x and one row y:
-//   sum_b min(x_b/|x|, y_b/|y|) / sum_b max(x_b/|x|, y_b/|y|).
-// Only the row's bins are visited (ascending): bins touched by the representative
-// alone contribute x_b/|x| to the max-sum, and their total is (T - sum_{b in row} x_b)/|x|
-// with T = sum_b x_b an exact integer - O(|row|) instead of O(|rep| + |row|).
-inline float similarity(const Representative& rep, const BinCount* rb, const BinCount* re,
-                        uint64_t rowSquares) {
+// Per-thread scratch of the pair evaluation.
+struct PairScratch {
+    std::vector<UIN> rowCount;                 // numBins, zero between calls
+    std::vector<float> maxValue, minValue;     // per node, valid where stamp == epoch
+    std::vector<uint32_t> stamp;
+    std::vector<int> dirty;
+    uint32_t epoch = 0;
+    PairScratch(size_t numBins, size_t nodes)
+        : rowCount(numBins, 0), maxValue(nodes), minValue(nodes), stamp(nodes, 0) {}
+};
+
+// Normalised weighted Jaccard similarity of the representative x and one row y,
+//   sum_b min(x_b/|x|, y_b/|y|) / sum_b max(x_b/|x|, y_b/|y|),
+// as executed by the reference (src/rowReordering.cu:235-293): only the leaves (threads)
+// that own one of the row's bins differ from the representative's cached tree.
+float similarity(const Representative& rep, const BinCount* rb, const BinCount* re, uint32_t rowSquares,
+                 PairScratch& sc) {
     if (rep.sumSquares == 0 && rowSquares == 0) return 1.0f;
     if (rep.sumSquares == 0 || rowSquares == 0) return 0.0f;
-    const float normRep = std::sqrt(static_cast<float>(rep.sumSquares));
+    const BlockSum& sum = rep.sum;
+    const UIN T = sum.threads;
     const float normRow = std::sqrt(static_cast<float>(rowSquares));
-    float minSum = 0.0f, maxShared = 0.0f;
-    uint64_t repInRow = 0;
-    for (const BinCount* it = rb; it != re; ++it) {
-        const UIN c = rep.count[it->bin];
-        const float x = static_cast<float>(c) / normRep;
-        const float y = static_cast<float>(it->count) / normRow;
-        minSum += std::fmin(x, y);
-        maxShared += std::fmax(x, y);
-        repInRow += c;
+    if (++sc.epoch == 0) {
+        std::fill(sc.stamp.begin(), sc.stamp.end(), 0u);
+        sc.epoch = 1;
     }
-    const float maxSum = maxShared + static_cast<float>(rep.total - repInRow) / normRep;
+    for (const BinCount* it = rb; it != re; ++it) sc.rowCount[it->bin] = it->count;
+    sc.dirty.clear();
+    for (const BinCount* it = rb; it != re; ++it) {
+        const UIN t = it->bin % T;
+        if (!sum.live[t] || sc.stamp[t] == sc.epoch) continue;
+        sc.stamp[t] = sc.epoch;
+        float mx = 0.0f, mn = 0.0f;
+        for (size_t b = t; b < rep.numBins; b += T) {
+            const float x = static_cast<float>(rep.count[b]) / rep.norm;
+            const float y = static_cast<float>(sc.rowCount[b]) / normRow;
+            mn = mn + std::fmin(x, y);
+            mx = mx + std::fmax(x, y);
+        }
+        sc.maxValue[t] = mx;
+        sc.minValue[t] = mn;
+        for (int p = sum.parent[t]; p >= 0 && sc.stamp[p] != sc.epoch; p = sum.parent[p]) {
+            sc.stamp[p] = sc.epoch;
+            sc.dirty.push_back(p);
+        }
+    }
+    for (const BinCount* it = rb; it != re; ++it) sc.rowCount[it->bin] = 0;
+    std::sort(sc.dirty.begin(), sc.dirty.end());
+    for (const int n : sc.dirty) {
+        const int a = sum.left[n], b = sum.right[n];
+        const bool da = sc.stamp[a] == sc.epoch, db = sc.stamp[b] == sc.epoch;
+        sc.maxValue[n] = (da ? sc.maxValue[a] : rep.maxTree[a]) + (db ? sc.maxValue[b] : rep.maxTree[b]);
+        sc.minValue[n] = (da ? sc.minValue[a] : 0.0f) + (db ? sc.minValue[b] : 0.0f);
+    }
+    const bool touched = sc.stamp[sum.root] == sc.epoch;
+    const float minSum = touched ? sc.minValue[sum.root] : 0.0f;
+    const float maxSum = touched ? sc.maxValue[sum.root] : rep.maxTree[sum.root];
     return minSum / maxSum;
 }
 
@@ -202,8 +316,9 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
     const UIN binWidth = block_size == 0 ? 16 : block_size;
     const size_t numBins = static_cast<size_t>(
         std::ceil(static_cast<float>(matrix.col()) / static_cast<float>(binWidth)));
+    const BlockSum blockSum(clusterThreads(numBins));
 
-    const RowEncodings enc = buildEncodings(matrix, binWidth);
+    const RowEncodings enc = buildEncodings(matrix, binWidth, blockSum);
 
     // rows in ascending dispersion, ties in ascending row id (stable)
     std::vector<UIN> order(rows);
@@ -218,19 +333,33 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
     while (firstNonEmpty < rows && enc.dispersion[order[firstNonEmpty]] == 0)
         cluster[firstNonEmpty++] = 0;
 
-    // inverted index: bin -> positions (ascending) of the non-empty rows touching it
+    // inverted index over the bins that count: bin -> positions (ascending) of the rows
+    // touching it.  A row that shares no such bin with the representative has min-sum 0,
+    // similarity 0, and is rejected for every alpha >= 0.
     std::vector<size_t> invOffsets(numBins + 1, 0);
-    for (const BinCount& bc : enc.items) ++invOffsets[bc.bin + 1];
+    for (const BinCount& bc : enc.items)
+        if (blockSum.binCounts(bc.bin)) ++invOffsets[bc.bin + 1];
     for (size_t b = 0; b < numBins; ++b) invOffsets[b + 1] += invOffsets[b];
-    std::vector<UIN> invItems(enc.items.size());
+    std::vector<UIN> invItems(invOffsets[numBins]);
     std::vector<size_t> invLen(numBins, 0);  // live length (lists are compacted lazily)
+    // rows whose counted sum of squares is zero: similarity 1 with a representative in the
+    // same state, 0 otherwise (src/rowReordering.cu:263-268)
+    std::vector<UIN> zeroSquarePositions;
     for (UIN pos = firstNonEmpty; pos < rows; ++pos) {
         const UIN row = order[pos];
+        if (enc.squares[row] == 0) {
+            zeroSquarePositions.push_back(pos);
+            continue;
+        }
         for (const BinCount* it = enc.begin(row); it != enc.end(row); ++it)
-            invItems[invOffsets[it->bin] + invLen[it->bin]++] = pos;
+            if (blockSum.binCounts(it->bin)) invItems[invOffsets[it->bin] + invLen[it->bin]++] = pos;
     }
 
-    Representative rep(numBins);
+    Representative rep(blockSum, numBins);
+    const int maxThreads = omp_get_max_threads();
+    std::vector<PairScratch> scratch;
+    scratch.reserve(maxThreads);
+    for (int t = 0; t < maxThreads; ++t) scratch.emplace_back(numBins, blockSum.nodes());
     std::vector<UIN> seenBy(rows, 0);  // last cluster id that queued this position
     std::vector<UIN> newBins, pending;
     std::priority_queue<UIN, std::vector<UIN>, std::greater<UIN>> candidates;
@@ -265,7 +394,7 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
         // (rows before the first accepted one of a chunk were judged with the right
         // representative; the rest of the chunk is re-judged after the merge).
         bool scanAll = scanEverything;
-        if (!scanAll) {
+        if (!scanAll && rep.sumSquares != 0) {
             size_t reach = 0;
             for (const UIN b : newBins) reach += invLen[b];
             scanAll = reach >= static_cast<size_t>(rows - start);
@@ -282,7 +411,8 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
 #pragma omp parallel for schedule(static) reduction(min : firstHit) if (n >= 64)
                 for (long long j = 0; j < static_cast<long long>(n); ++j) {
                     const UIN row = order[pending[i + j]];
-                    if (similarity(rep, enc.begin(row), enc.end(row), enc.squares[row]) > alpha)
+                    if (similarity(rep, enc.begin(row), enc.end(row), enc.squares[row],
+                                   scratch[omp_get_thread_num()]) > alpha)
                         firstHit = std::min(firstHit, j);
                 }
                 if (firstHit == static_cast<long long>(n)) {
@@ -294,13 +424,25 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
                 rep.add(enc.begin(order[pos]), enc.end(order[pos]), newBins);
                 i += static_cast<size_t>(firstHit) + 1;
             }
+        } else if (rep.sumSquares == 0) {
+            // nothing of the seed row counts: it matches exactly the rows in the same state,
+            // and merging them leaves the representative in that state
+            if (1.0f > alpha) {
+                size_t keep = 0;
+                for (const UIN pos : zeroSquarePositions) {
+                    if (cluster[pos] != NULL_VALUE) continue;
+                    if (pos > start) cluster[pos] = clusterId;
+                    else zeroSquarePositions[keep++] = pos;
+                }
+                zeroSquarePositions.resize(keep);
+            }
         } else {
             for (const UIN b : newBins) enqueueBin(b, start, clusterId);
             while (!candidates.empty()) {
                 const UIN pos = candidates.top();
                 candidates.pop();
                 const UIN row = order[pos];
-                if (similarity(rep, enc.begin(row), enc.end(row), enc.squares[row]) > alpha) {
+                if (similarity(rep, enc.begin(row), enc.end(row), enc.squares[row], scratch[0]) > alpha) {
                     cluster[pos] = clusterId;
                     rep.add(enc.begin(row), enc.end(row), newBins);
                     for (const UIN b : newBins) enqueueBin(b, pos, clusterId);
@@ -316,8 +458,11 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
     std::iota(positions.begin(), positions.end(), 0);
     std::stable_sort(positions.begin(), positions.end(),
                      [&](UIN a, UIN b) { return cluster[a] < cluster[b]; });
+    // The reference reads the *sorted* id array at the unsorted position of its last element
+    // (src/rowReordering.cu:985-992: sort_by_key sorts cluster_ids in place, then
+    // cluster_ids[indices[rows - 1]]); the logged count follows that, quirk included.
     num_clusters = rows == 0 ? 0
-                             : static_cast<int>(cluster[positions[rows - 1]]) +
+                             : static_cast<int>(cluster[positions[positions[rows - 1]]]) +
                                    (firstNonEmpty != 0 ? 1 : 0);
 
     std::vector<UIN> permutation;

@@ -80,6 +80,26 @@ float bsmr_pipeline_col_reordering_ms(const bsmr_pipeline *p);
 float bsmr_pipeline_rphm_ms(const bsmr_pipeline *p);
 /* check_rphm (src/BSMR.cpp:932-953): 1 = all invariants hold */
 int bsmr_pipeline_check(const bsmr_pipeline *p, const bsmr_csr *m, float delta);
+/* evaluationReordering (src/BSMR.cpp:826-930) +
+ * calculateNumDenseBlocksAndAverageDensityInOriginalMatrix (:955-994): the reordering
+ * statistics the reference logs per (alpha, delta) - `original_*`, `bsmr_numDenseBlock`,
+ * `bsmr_averageDensity`, `bsmr_num{Dense,Sparse}ThreadBlocks`, `bsmr_num{Dense,Sparse}Data`
+ * - plus RPHM::maxNumDenseColBlocksInRowPanel (include/BSMR.hpp:124), whose quarter is
+ * the reference's `gridDim_dense.y` (src/sddmmKernel.cu:2570-2574). */
+typedef struct bsmr_reordering_report {
+    int32_t  original_num_dense_blocks;
+    float    original_average_density;
+    int32_t  num_dense_blocks;
+    float    average_density;
+    int32_t  num_dense_thread_blocks;
+    int32_t  num_sparse_thread_blocks;
+    int32_t  num_dense_data;
+    int32_t  num_sparse_data;
+    uint32_t max_dense_blocks_per_panel;
+    uint32_t max_sparse_blocks_per_panel;
+} bsmr_reordering_report;
+int bsmr_pipeline_evaluate(const bsmr_pipeline *p, const bsmr_csr *m, float delta,
+                           bsmr_reordering_report *out);
 /* Device plan of the RPHM (NULL when built host-only); status of its creation. */
 bsmr_plan *bsmr_pipeline_plan(const bsmr_pipeline *p);
 int bsmr_pipeline_plan_status(const bsmr_pipeline *p);

@@ -6,10 +6,13 @@ dense/sparse split -> RPHM index arrays), written for small inputs only.  The
 product's C++ pipeline (bsmr-sddmm_amd/src) is checked against it; nothing in
 bsmr-sddmm_amd/ may import this file.
 
-PARITY UNPINNED: the reference has no tests or golden vectors for these
-functions and its host code cannot be built in this image without stand-ins
-(see oracle/sddmm_oracle.c header), so this is a line-cited restatement only.
-Citations are relative to the reference checkout (/root/reference).
+Pinning: the reference has no tests and its host code cannot be built in this image
+without stand-ins, but it ships the logs of its own sweep over SuiteSparse
+(scripts/results_suiteSparse_dataset/BSMR_results).  Six of those matrices have a
+closed-form pattern; tests/test_reference_logs.py rebuilds them and checks every logged
+integer against the C restatement of the clustering (oracle/clustering_oracle.c) and
+the product pipeline, and tests/test_oracle.py checks this file against that C
+restatement on small inputs.  Citations are relative to the reference checkout.
 """
 from __future__ import annotations
 
@@ -117,29 +120,54 @@ def encodings(rows, cols, ro, ci, bs):
     return enc, disp
 
 
+def cluster_threads(nb: int) -> int:
+    # src/rowReordering.cu:912-922
+    if nb < 32:
+        return 32
+    cand = 32 * int(math.ceil(np.float32(nb // 4) / np.float32(32)))
+    return min(1024, max(32, cand))
+
+
+def block_sum(partials: np.ndarray):
+    """include/cudaUtil.cuh:14-45 as executed: per-warp balanced tree (shuffle-xor, lane 0),
+    then `for (s = T/64; s >= 1; s >>= 1) v[w] += v[w+s]` - warps that loop never reads are
+    simply not part of the result (T/32 not a power of two)."""
+    v = partials.reshape(-1, 32).copy()
+    step = 1
+    while step < 32:
+        v[:, ::2 * step] = v[:, ::2 * step] + v[:, step::2 * step]
+        step *= 2
+    w = v[:, 0].copy()
+    s = partials.size // 64
+    while s >= 1:
+        w[:s] = w[:s] + w[s:2 * s]
+        s >>= 1
+    return w[0]
+
+
+def per_thread(values: np.ndarray, threads: int) -> np.ndarray:
+    """thread t accumulates bins t, t+T, t+2T, ... in that order"""
+    pad = (-values.size) % threads
+    v = np.concatenate([values, np.zeros(pad, dtype=values.dtype)]).reshape(-1, threads)
+    acc = np.zeros(threads, dtype=values.dtype)
+    for row in v:
+        acc = (acc + row).astype(values.dtype)
+    return acc
+
+
 def similarity(rep, cmp_):
-    # :235-293.  Integer sums of squares; fp32 norms, quotients and sums.
-    # Summation order (the GPU uses a block tree over all bins): the compared row's
-    # bins in ascending order; bins touched by the representative alone add
-    # (T - sum_{b in row} rep_b) / |rep| to the max-sum in one term, T = sum(rep) exact.
-    sx = int(np.sum(rep * rep))
-    sy = int(np.sum(cmp_ * cmp_))
+    # :235-293 with every sum taken the way the block takes it.
+    threads = cluster_threads(rep.size)
+    sx = int(block_sum(per_thread((rep * rep).astype(np.uint32), threads)))   # UIN, wraps
+    sy = int(block_sum(per_thread((cmp_ * cmp_).astype(np.uint32), threads)))
     if sx == 0 and sy == 0:
         return np.float32(1.0)
     if sx == 0 or sy == 0:
         return np.float32(0.0)
-    nx = np.sqrt(np.float32(sx))
-    ny = np.sqrt(np.float32(sy))
-    mn = np.float32(0.0)
-    mx = np.float32(0.0)
-    rep_in_row = 0
-    for b in np.nonzero(cmp_ > 0)[0]:
-        a = np.float32(rep[b]) / nx
-        c = np.float32(cmp_[b]) / ny
-        mn = np.float32(mn + min(a, c))
-        mx = np.float32(mx + max(a, c))
-        rep_in_row += int(rep[b])
-    mx = np.float32(mx + np.float32(int(np.sum(rep)) - rep_in_row) / nx)
+    a = rep.astype(np.float32) / np.sqrt(np.float32(sx))
+    c = cmp_.astype(np.float32) / np.sqrt(np.float32(sy))
+    mn = block_sum(per_thread(np.minimum(a, c), threads))
+    mx = block_sum(per_thread(np.maximum(a, c), threads))
     return np.float32(mn / mx)
 
 
@@ -174,7 +202,9 @@ def row_reordering(rows, cols, ro, ci, alpha, bs):
         cid += 1
     pos = np.argsort(cluster, kind="stable")  # :988-995
     perm = order[pos]
-    num_clusters = int(cluster[pos[-1]]) + (1 if z != 0 else 0) if rows else 0  # :996
+    # :985-992: sort_by_key sorts cluster_ids in place, then cluster_ids[indices[rows-1]]
+    # reads the SORTED ids at the unsorted position of the last element
+    num_clusters = int(cluster[pos][pos[-1]]) + (1 if z != 0 else 0) if rows else 0
     # :1082-1090 drop leading empty rows
     k = 0
     while k < rows and ro[perm[k] + 1] - ro[perm[k]] == 0:

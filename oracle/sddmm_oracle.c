@@ -5,12 +5,14 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file;
  * the product (bsmr-sddmm_amd/) never links, imports or calls it.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for
- * this path and its own host code cannot be built in this
- * image without writing stand-ins (cuda_fp16.h needs the absent <nv/target>,
- * cudaErrorCheck.cuh needs the absent <curand.h>, linking needs libcudart and
- * CUDA Thrust).  So every function below is a restatement that cites the
- * reference lines it follows; nothing here was checked against reference output.
+ * PARITY UNPINNED for the values computed here: the reference ships no golden
+ * output vectors (its published logs hold GFLOP/s only) and its own host code cannot
+ * be built in this image without writing stand-ins (cuda_fp16.h needs the absent
+ * <nv/target>, cudaErrorCheck.cuh needs the absent <curand.h>, linking needs
+ * libcudart and CUDA Thrust).  So every function below is a restatement that cites
+ * the reference lines it follows.  (The host pipeline is a different story: it is
+ * pinned by the reference's published logs, see oracle/clustering_oracle.c and
+ * tests/test_reference_logs.py.)
  *
  * Conventions (reference src/main.cu:23-27): A is M x K row-major, B is K x N
  * column-major with ld = K (so column j is the K contiguous floats B[j*K ..]),

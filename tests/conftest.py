@@ -57,6 +57,34 @@ class Oracle:
         L.oracle_dense_f32_twin.argtypes = [C.c_uint32] * 2 + [vp] * 5
         L.oracle_dense_lowp_model.argtypes = [C.c_int] + [C.c_uint32] * 2 + [vp] * 5
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_bsa_row_reordering.argtypes = [C.c_uint32] * 2 + [vp, vp, C.c_uint32, C.c_float, vp, vp, vp]
+        L.oracle_bsa_row_reordering.restype = C.c_int
+        L.oracle_cluster_similarity.argtypes = [vp, vp, C.c_uint32]
+        L.oracle_cluster_similarity.restype = C.c_float
+        L.oracle_cluster_threads.argtypes = [C.c_uint32]
+        L.oracle_cluster_threads.restype = C.c_uint32
+        L.oracle_cluster_bin_mask.argtypes = [C.c_uint32, vp]
+
+    def bsa_row_reordering(self, rows, cols, ro, ci, bin_width, alpha):
+        """oracle/clustering_oracle.c: (reorderedRows, numClusters) as the reference computes them"""
+        ro = np.ascontiguousarray(ro, dtype=np.uint32)
+        ci = np.ascontiguousarray(ci, dtype=np.uint32)
+        perm = np.zeros(max(rows, 1), dtype=np.uint32)
+        n_out, clusters = C.c_uint32(0), C.c_int32(0)
+        st = self.lib.oracle_bsa_row_reordering(rows, cols, self._p(ro), self._p(ci), bin_width, alpha,
+                                                self._p(perm), C.byref(n_out), C.byref(clusters))
+        assert st == 0, "oracle could not allocate the rows x bins table"
+        return perm[:n_out.value].copy(), clusters.value
+
+    def cluster_similarity(self, rep, cmp_):
+        rep = np.ascontiguousarray(rep, dtype=np.uint32)
+        cmp_ = np.ascontiguousarray(cmp_, dtype=np.uint32)
+        return float(self.lib.oracle_cluster_similarity(self._p(rep), self._p(cmp_), rep.size))
+
+    def cluster_bin_mask(self, num_bins):
+        mask = np.zeros(num_bins, dtype=np.uint8)
+        self.lib.oracle_cluster_bin_mask(num_bins, self._p(mask))
+        return mask.astype(bool)
 
     @staticmethod
     def _p(a):

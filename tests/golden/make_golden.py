@@ -2,8 +2,8 @@
 """Generates tests/golden/pipeline_*.json from the numpy oracle (oracle/bsmr_oracle.py).
 
 These fixtures freeze the oracle's outputs on tiny seeded inputs so that later edits
-cannot drift silently.  They are NOT reference output: the reference has no golden
-vectors and cannot be built here (DESIGN.md "Oracle"), so parity stays 'unpinned'.
+cannot drift silently.  They are NOT reference output (that is reference_logs.json,
+which pins the same oracle on real matrices: tests/test_reference_logs.py).
 Run from the repo root:  python tests/golden/make_golden.py
 """
 import json
