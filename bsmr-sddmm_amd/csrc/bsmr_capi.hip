@@ -70,7 +70,8 @@ struct bsmr_plan {
     uint16_t* B16 = nullptr;
     uint32_t reservedK = 0;
 
-    int sparseLpe = 8;
+    int sparseLpe = 0;             // 0 = per-K tuned shape (sparseShape); BSMR_SPARSE_LPE = 4 / 8 / 16 forces the run-time loop
+    bool sparseLowp = true;        // residue from the fp16/bf16 copies whenever the conversion pass runs (BSMR_SPARSE_LOWP=0: always fp32)
     bool convertInKernel = false;  // dense part so small that the full operand conversion pass does not pay
     int denseBatch = 0;            // blocks per LDS batch at K = 128 (0 = default)
     bool useStream = true;         // streaming kernel for ungrouped plans (BSMR_DENSE_STREAM=0 disables)
@@ -321,16 +322,34 @@ int launchDense32(const bsmr_plan* p, uint32_t K, const float* A, const float* B
     return BSMR_OK;
 }
 
-template <int LPE>
-int launchSparseLpe(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P,
-                    hipStream_t s) {
+// Lanes per entry of the residue kernels.  Tuned shapes (all of a lane's column chunks in
+// flight at once) exist for K = 32 ... 512; BSMR_SPARSE_LPE or any other K takes the
+// run-time loop.  fp32: chunk = 4 elements, low precision: chunk = 8 elements.
+struct SparseShape {
+    int lpe;  // lanes per entry
+    int cpl;  // chunks per lane when tuned, 0 = run-time loop
+};
+SparseShape sparseShape(const bsmr_plan* p, uint32_t K, bool lowp) {
+    const uint32_t chunks = K / (lowp ? 8u : 4u);
+    if (p->sparseLpe == 0) {
+        const int lpe = lowp ? (K <= 128 ? 4 : 8) : (K <= 64 ? 4 : (K <= 256 ? 8 : 16));
+        if (K >= 32 && K <= 512 && (K & (K - 1)) == 0) return {lpe, (int)(chunks / lpe)};
+        return {8, 0};
+    }
+    int lpe = p->sparseLpe;
+    while (lpe > 1 && (uint32_t)lpe > chunks) lpe >>= 1;
+    return {lpe, 0};
+}
+
+template <int LPE, int CPL>
+int launchSparseT(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, hipStream_t s) {
     const size_t lds = (size_t)16 * (K + bsmr::kSparseLdsPad) * sizeof(float);
     const uint32_t wgs = p->numSparseItems;  // no padding: every workgroup reads its item
     if (lds <= 64 * 1024) {
-        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, true>), dim3(wgs), dim3(bsmr::kThreads), lds, s, A, B,
+        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, true, CPL>), dim3(wgs), dim3(bsmr::kThreads), lds, s, A, B,
                            K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P);
     } else {
-        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, false>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B,
+        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, false, CPL>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B,
                            K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P);
     }
     BSMR_HIP(hipGetLastError());
@@ -339,13 +358,49 @@ int launchSparseLpe(const bsmr_plan* p, uint32_t K, const float* A, const float*
 
 int launchSparse(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, hipStream_t s) {
     if (p->numSparseItems == 0) return BSMR_OK;
-    // never more lanes per entry than float4 chunks in a column
-    int lpe = p->sparseLpe;
-    while (lpe > 1 && (uint32_t)lpe > K / 4) lpe >>= 1;
-    switch (lpe) {
-    case 16: return launchSparseLpe<16>(p, K, A, B, P, s);
-    case 4: return launchSparseLpe<4>(p, K, A, B, P, s);
-    default: return launchSparseLpe<8>(p, K, A, B, P, s);
+    const SparseShape sh = sparseShape(p, K, false);
+    switch (sh.lpe * 100 + sh.cpl) {
+    case 402: return launchSparseT<4, 2>(p, K, A, B, P, s);    // K = 32
+    case 404: return launchSparseT<4, 4>(p, K, A, B, P, s);    // K = 64
+    case 804: return launchSparseT<8, 4>(p, K, A, B, P, s);    // K = 128
+    case 808: return launchSparseT<8, 8>(p, K, A, B, P, s);    // K = 256
+    case 1608: return launchSparseT<16, 8>(p, K, A, B, P, s);  // K = 512
+    case 1600: return launchSparseT<16, 0>(p, K, A, B, P, s);
+    case 400: return launchSparseT<4, 0>(p, K, A, B, P, s);
+    default: return launchSparseT<8, 0>(p, K, A, B, P, s);
+    }
+}
+
+template <int LPE, int CPL, int MODE>
+int launchSparse16T(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
+                    hipStream_t s) {
+    const size_t lds = (size_t)16 * (2u * K + bsmr::kSparseLdsPad16);
+    const uint32_t wgs = p->numSparseItems;
+    if (lds <= 64 * 1024) {
+        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, true, CPL>), dim3(wgs), dim3(bsmr::kThreads), lds, s,
+                           A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P);
+    } else {
+        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, false, CPL>), dim3(wgs), dim3(bsmr::kThreads), 0, s,
+                           A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P);
+    }
+    BSMR_HIP(hipGetLastError());
+    return BSMR_OK;
+}
+
+template <int MODE>
+int launchSparse16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
+                   hipStream_t s) {
+    if (p->numSparseItems == 0) return BSMR_OK;
+    const SparseShape sh = sparseShape(p, K, true);
+    switch (sh.lpe * 100 + sh.cpl) {
+    case 401: return launchSparse16T<4, 1, MODE>(p, K, A16, B16, P, s);  // K = 32
+    case 402: return launchSparse16T<4, 2, MODE>(p, K, A16, B16, P, s);  // K = 64
+    case 404: return launchSparse16T<4, 4, MODE>(p, K, A16, B16, P, s);  // K = 128
+    case 804: return launchSparse16T<8, 4, MODE>(p, K, A16, B16, P, s);  // K = 256
+    case 808: return launchSparse16T<8, 8, MODE>(p, K, A16, B16, P, s);  // K = 512
+    case 1600: return launchSparse16T<16, 0, MODE>(p, K, A16, B16, P, s);
+    case 400: return launchSparse16T<4, 0, MODE>(p, K, A16, B16, P, s);
+    default: return launchSparse16T<8, 0, MODE>(p, K, A16, B16, P, s);
     }
 }
 
@@ -396,6 +451,12 @@ int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P
             st = mode == BSMR_COMPUTE_F16 ? launchDense16<0>(p, K, p->A16, p->B16, P, s)
                                           : launchDense16<1>(p, K, p->A16, p->B16, P, s);
             if (st != BSMR_OK) return st;
+        }
+        if (p->sparseLowp) {
+            if (which & 4)
+                return mode == BSMR_COMPUTE_F16 ? launchSparse16<0>(p, K, p->A16, p->B16, P, s)
+                                                : launchSparse16<1>(p, K, p->A16, p->B16, P, s);
+            return BSMR_OK;
         }
     }
     if ((which & 4) && (st = launchSparse(p, K, A, B, P, s)) != BSMR_OK) return st;
@@ -539,8 +600,9 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         p->numDenseEntries = pk.numDenseEntries;
         p->numSparseEntries = pk.numSparseEntries;
         p->numSparseItems = (uint32_t)pk.sparseItems.size();
-        p->sparseLpe = envInt("BSMR_SPARSE_LPE", 8);
-        if (p->sparseLpe != 4 && p->sparseLpe != 8 && p->sparseLpe != 16) p->sparseLpe = 8;
+        p->sparseLowp = envInt("BSMR_SPARSE_LOWP", 1) != 0;
+        p->sparseLpe = envInt("BSMR_SPARSE_LPE", 0);
+        if (p->sparseLpe != 4 && p->sparseLpe != 8 && p->sparseLpe != 16) p->sparseLpe = 0;
         p->denseBatch = envInt("BSMR_DENSE_BATCH", 0);
         p->useStream = envInt("BSMR_DENSE_STREAM", 1) != 0;
         // full conversion moves 6 bytes per operand element; the in-kernel path reads each
@@ -603,6 +665,7 @@ int bsmr_plan_get_stats(const bsmr_plan* p, bsmr_plan_stats* out) {
     out->grouped_group_size = p->fmt[1].H;
     out->grouped_dense_tiles = p->fmt[1].numTiles;
     out->grouped_union_columns = p->fmt[1].unionColumns;
+    out->sparse_lowp = p->sparseLowp && f.numItems && !p->convertInKernel && p->numSparseItems ? 1 : 0;
     return BSMR_OK;
 }
 
@@ -613,6 +676,17 @@ int bsmr_plan_dense_choice(const bsmr_plan* plan, uint32_t K, uint32_t* group_si
     if (group_size) *group_size = f.H ? f.H : 1;
     if (tiles) *tiles = f.numTiles;
     if (union_columns) *union_columns = f.unionColumns;
+    return BSMR_OK;
+}
+
+int bsmr_plan_sparse_choice(const bsmr_plan* plan, uint32_t K, int mode, uint32_t* lanes_per_entry,
+                            uint32_t* low_precision) {
+    if (!plan) return BSMR_ERR_INVALID_ARG;
+    if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
+    const bool lowp = mode != BSMR_COMPUTE_F32 && plan->sparseLowp && plan->fmt[0].numItems &&
+                      !plan->convertInKernel && plan->numSparseItems;
+    if (lanes_per_entry) *lanes_per_entry = (uint32_t)sparseShape(plan, K, lowp).lpe;
+    if (low_precision) *low_precision = lowp ? 1u : 0u;
     return BSMR_OK;
 }
 
@@ -650,7 +724,8 @@ int bsmr_sddmm_lowp(bsmr_plan* plan, uint32_t K, const void* A16, const void* B1
     if (!plan || !A16 || !B16 || !P) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     if (mode != BSMR_COMPUTE_F16 && mode != BSMR_COMPUTE_BF16) return BSMR_ERR_INVALID_ARG;
-    if (plan->numSparseItems && (!A || !B)) return BSMR_ERR_INVALID_ARG;  // sparse residue needs fp32 operands
+    const bool residueLowp = plan->sparseLowp && plan->fmt[0].numItems && !plan->convertInKernel;
+    if (plan->numSparseItems && !residueLowp && (!A || !B)) return BSMR_ERR_INVALID_ARG;  // fp32 residue
     BSMR_HIP(hipSetDevice(plan->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     int st = mode == BSMR_COMPUTE_F16
@@ -659,6 +734,10 @@ int bsmr_sddmm_lowp(bsmr_plan* plan, uint32_t K, const void* A16, const void* B1
                  : launchDense16<1>(plan, K, static_cast<const uint16_t*>(A16),
                                     static_cast<const uint16_t*>(B16), P, s);
     if (st != BSMR_OK) return st;
+    if (residueLowp)
+        return mode == BSMR_COMPUTE_F16
+                   ? launchSparse16<0>(plan, K, static_cast<const uint16_t*>(A16), static_cast<const uint16_t*>(B16), P, s)
+                   : launchSparse16<1>(plan, K, static_cast<const uint16_t*>(A16), static_cast<const uint16_t*>(B16), P, s);
     return launchSparse(plan, K, A, B, P, s);
 }
 

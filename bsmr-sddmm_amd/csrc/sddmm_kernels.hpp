@@ -652,7 +652,9 @@ denseGroupsF32(const float* __restrict__ A, const float* __restrict__ B, uint32_
 // ---------------------------------------------------------------------------
 constexpr int kSparseLdsPad = 4;  // floats
 
-template <int LPE, bool A_IN_LDS>
+// CPL > 0: K = 4 * LPE * CPL, every lane's CPL column chunks are requested before the first
+// is used (the residue is a gather: what matters is bytes in flight); CPL = 0: any K.
+template <int LPE, bool A_IN_LDS, int CPL = 0>
 __global__ void __launch_bounds__(kThreads)
 sparseEntries(const float* __restrict__ A, const float* __restrict__ B, uint32_t K,
               const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ entryCol,
@@ -689,13 +691,112 @@ sparseEntries(const float* __restrict__ A, const float* __restrict__ B, uint32_t
         const float* aRow = A_IN_LDS ? panelA + row * ldsStride
                                      : A + (size_t)panelRows[item.panel * 16u + row] * K;
         float acc = 0.f;
-        for (uint32_t q = t; q < chunks; q += LPE) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bCol + q * 4u);
-            const f32x4 av = *reinterpret_cast<const f32x4*>(aRow + q * 4u);
-            acc = __builtin_fmaf(av[0], bv[0], acc);
-            acc = __builtin_fmaf(av[1], bv[1], acc);
-            acc = __builtin_fmaf(av[2], bv[2], acc);
-            acc = __builtin_fmaf(av[3], bv[3], acc);
+        if constexpr (CPL > 0) {
+            f32x4 bv[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) bv[c] = *reinterpret_cast<const f32x4*>(bCol + (t + c * LPE) * 4u);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(aRow + (t + c * LPE) * 4u);
+                acc = __builtin_fmaf(av[0], bv[c][0], acc);
+                acc = __builtin_fmaf(av[1], bv[c][1], acc);
+                acc = __builtin_fmaf(av[2], bv[c][2], acc);
+                acc = __builtin_fmaf(av[3], bv[c][3], acc);
+            }
+        } else {
+            for (uint32_t q = t; q < chunks; q += LPE) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bCol + q * 4u);
+                const f32x4 av = *reinterpret_cast<const f32x4*>(aRow + q * 4u);
+                acc = __builtin_fmaf(av[0], bv[0], acc);
+                acc = __builtin_fmaf(av[1], bv[1], acc);
+                acc = __builtin_fmaf(av[2], bv[2], acc);
+                acc = __builtin_fmaf(av[3], bv[3], acc);
+            }
+        }
+#pragma unroll
+        for (int off = LPE / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, LPE);
+        if (live && t == 0) P[entryDst[idx]] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Sparse residue from the fp16 / bf16 operand copies.  Used when the conversion pass runs
+// anyway (the plan has a dense part): the residue is bound by the rate at which B columns
+// can be gathered from L2 (~17-19 TB/s chip-wide on MI355X, MI355X_MICROARCH.md "Indexed
+// rows"), so halving the bytes per column is what makes it faster.  Same structure as
+// sparseEntries; 16-byte chunks now hold 8 elements and go through v_dot2c_f32_{f16,bf16}
+// (products exact, fp32 accumulation).  Accuracy class = the dense path's.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kSparseLdsPad16 = 16;  // bytes
+
+template <int MODE>
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
+    if constexpr (MODE == 0) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), acc, false);
+    } else {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, a), __builtin_bit_cast(b2, b), acc, false);
+    }
+}
+
+template <int LPE, int MODE, bool A_IN_LDS, int CPL = 0>
+__global__ void __launch_bounds__(kThreads)
+sparseEntriesLowp(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, uint32_t K,
+                  const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ entryCol,
+                  const uint32_t* __restrict__ entryDst, const uint8_t* __restrict__ entryRow,
+                  const SparseItem* __restrict__ items, float* __restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t panelA16[];
+    const SparseItem item = items[xcdContiguous(blockIdx.x, gridDim.x)];
+    const uint32_t chunks = K >> 3;  // 16-byte chunks (8 elements) per row
+    const uint32_t ldsStride = 2u * K + kSparseLdsPad16;
+
+    if constexpr (A_IN_LDS) {
+        for (uint32_t i = threadIdx.x; i < 16u * chunks; i += kThreads) {
+            const uint32_t row = i / chunks, q = i - row * chunks;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(
+                A16 + (size_t)panelRows[item.panel * 16u + row] * K + q * 8u);
+            *reinterpret_cast<u32x4*>(panelA16 + row * ldsStride + q * 16u) = v;
+        }
+        __syncthreads();
+    }
+
+    constexpr uint32_t groups = kThreads / LPE;
+    const uint32_t group = threadIdx.x / LPE;
+    const uint32_t t = threadIdx.x % LPE;
+    const uint32_t rounds = (item.count + groups - 1) / groups;
+    for (uint32_t round = 0; round < rounds; ++round) {
+        const uint32_t e = round * groups + group;
+        const bool live = e < item.count;
+        const uint32_t idx = item.start + (live ? e : 0u);
+        const uint32_t col = entryCol[idx];
+        const uint32_t row = entryRow[idx];
+        const uint16_t* bCol = B16 + (size_t)col * K;
+        const uint8_t* aRow = A_IN_LDS
+                                  ? panelA16 + row * ldsStride
+                                  : reinterpret_cast<const uint8_t*>(A16 + (size_t)panelRows[item.panel * 16u + row] * K);
+        float acc = 0.f;
+        if constexpr (CPL > 0) {  // K = 8 * LPE * CPL
+            u32x4 bv[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) bv[c] = *reinterpret_cast<const u32x4*>(bCol + (t + c * LPE) * 8u);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const u32x4 av = *reinterpret_cast<const u32x4*>(aRow + (t + c * LPE) * 16u);
+                acc = dot2<MODE>(av[0], bv[c][0], acc);
+                acc = dot2<MODE>(av[1], bv[c][1], acc);
+                acc = dot2<MODE>(av[2], bv[c][2], acc);
+                acc = dot2<MODE>(av[3], bv[c][3], acc);
+            }
+        } else {
+            for (uint32_t q = t; q < chunks; q += LPE) {
+                const u32x4 bv = *reinterpret_cast<const u32x4*>(bCol + q * 8u);
+                const u32x4 av = *reinterpret_cast<const u32x4*>(aRow + q * 16u);
+                acc = dot2<MODE>(av[0], bv[0], acc);
+                acc = dot2<MODE>(av[1], bv[1], acc);
+                acc = dot2<MODE>(av[2], bv[2], acc);
+                acc = dot2<MODE>(av[3], bv[3], acc);
+            }
         }
 #pragma unroll
         for (int off = LPE / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, LPE);

@@ -50,7 +50,7 @@ class PlanStats(C.Structure):
                 ("device_index_bytes", C.c_uint64), ("group_size", C.c_uint32),
                 ("num_dense_tiles", C.c_uint64), ("union_columns", C.c_uint64),
                 ("grouped_group_size", C.c_uint32), ("grouped_dense_tiles", C.c_uint64),
-                ("grouped_union_columns", C.c_uint64)]
+                ("grouped_union_columns", C.c_uint64), ("sparse_lowp", C.c_uint64)]
 
 
 class ReorderingReport(C.Structure):
@@ -82,6 +82,8 @@ HIP_SYMBOLS = {
     "bsmr_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RphmDesc)]),
     "bsmr_plan_destroy": (C.c_int, [C.c_void_p]),
     "bsmr_plan_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
+    "bsmr_plan_sparse_choice": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_uint32)]),
     "bsmr_plan_dense_choice": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64)]),
     "bsmr_plan_reserve": (C.c_int, [C.c_void_p, C.c_uint32]),
@@ -312,6 +314,11 @@ class Pipeline:
         s = PlanStats()
         _check(hip().bsmr_plan_get_stats(self.plan, C.byref(s)), "bsmr_plan_get_stats")
         return {k: getattr(s, k) for k, _ in PlanStats._fields_}
+
+    def sparse_choice(self, K: int, mode=COMPUTE_F16) -> dict:
+        lanes, lowp = C.c_uint32(0), C.c_uint32(0)
+        _check(hip().bsmr_plan_sparse_choice(self.plan, K, mode, C.byref(lanes), C.byref(lowp)), "sparse_choice")
+        return {"lanes_per_entry": lanes.value, "low_precision": bool(lowp.value)}
 
     def dense_choice(self, K: int) -> dict:
         """Dense format used by a call with inner dimension K."""

@@ -90,6 +90,7 @@ typedef struct bsmr_plan_stats {
     uint32_t grouped_group_size;
     uint64_t grouped_dense_tiles;
     uint64_t grouped_union_columns;
+    uint64_t sparse_lowp;             /* 1: in the F16/BF16 modes the residue reads the converted operands too */
 } bsmr_plan_stats;
 
 /* Kernel timings of the last bsmr_sddmm_timed call, milliseconds per iteration. */
@@ -124,6 +125,12 @@ int bsmr_plan_get_stats(const bsmr_plan *plan, bsmr_plan_stats *out);
 int bsmr_plan_dense_choice(const bsmr_plan *plan, uint32_t K, uint32_t *group_size,
                            uint64_t *tiles, uint64_t *union_columns);
 
+/* How the sparse residue of a call (K, compute_mode) will run: lanes that share one entry's
+ * K-long dot product (the fp32 summation order of the residue depends on it; the CPU twin in
+ * oracle/sddmm_oracle.c takes the same number) and whether it reads the fp16/bf16 copies. */
+int bsmr_plan_sparse_choice(const bsmr_plan *plan, uint32_t K, int compute_mode,
+                            uint32_t *lanes_per_entry, uint32_t *low_precision);
+
 /* Grow the plan's operand workspace for inner dimension K now (otherwise it
  * grows on first use, which allocates and therefore must not happen inside a
  * stream capture). */
@@ -147,8 +154,9 @@ int bsmr_sddmm_timed(bsmr_plan *plan, uint32_t K, const float *A_dev, const floa
 int bsmr_convert_operands(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev,
                           void *A16_dev, void *B16_dev, int compute_mode, void *stream);
 
-/* SDDMM on pre-converted operands.  The dense path reads A16/B16; the sparse
- * residual path reads A_dev/B_dev (fp32) when given, else widens A16/B16. */
+/* SDDMM on pre-converted operands.  The dense path reads A16/B16.  The sparse residue reads
+ * them too when bsmr_plan_stats.sparse_lowp is 1 (A_dev/B_dev may then be NULL); otherwise it
+ * needs the fp32 A_dev/B_dev. */
 int bsmr_sddmm_lowp(bsmr_plan *plan, uint32_t K, const void *A16_dev, const void *B16_dev,
                     const float *A_dev, const float *B_dev, float *P_dev, int compute_mode,
                     void *stream);

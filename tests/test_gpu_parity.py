@@ -42,10 +42,13 @@ def dense_flags(pipe):
     return flags
 
 
-def expected_twin(oracle, pipe, K, ro, ci, A, B, mode, lpe=8):
+def expected_twin(oracle, pipe, K, ro, ci, A, B, mode, lpe=None):
     M = pipe.csr.rows
     flags = dense_flags(pipe).astype(bool)
-    sparse = oracle.sparse_twin(M, K, min(lpe, K // 4), ro, ci, A, B)
+    choice = pipe.sparse_choice(K, mode)
+    if lpe is not None and not choice["low_precision"]:
+        assert choice["lanes_per_entry"] == min(lpe, K // 4)      # BSMR_SPARSE_LPE was honoured
+    sparse = oracle.sparse_twin(M, K, choice["lanes_per_entry"], ro, ci, A, B)
     if mode == 2:
         dense = oracle.dense_f32_twin(M, K, ro, ci, A, B)
         return np.where(flags, dense, sparse), flags, None
@@ -76,7 +79,17 @@ def check_case(eng, oracle, rows, cols, ro, ci, K, alpha, delta, mode, row_mode=
         assert np.array_equal(got.view(np.uint32), twin.view(np.uint32)), "F32 mode is not bit exact"
     else:
         s = ~flags
-        assert np.array_equal(got[s].view(np.uint32), twin[s].view(np.uint32)), "sparse path not bit exact"
+        lowp_residue = bool(pipe.plan_stats()["sparse_lowp"])
+        assert lowp_residue == pipe.sparse_choice(K, mode)["low_precision"]
+        if lowp_residue:
+            # residue computed from the converted operands (v_dot2c chain + butterfly): same
+            # yardstick as the dense path - rounded operands, exact products, fp64 sum
+            absdot = oracle.sddmm_f64(rows, K, ro, ci, np.abs(A), np.abs(B))
+            err = np.abs(got[s].astype(np.float64) - model[s])
+            bound = (K / 16 + 8) * 2.0 ** -23
+            assert (err <= bound * absdot[s] + 1e-30).all(), f"lowp residue error {err.max()}"
+        else:
+            assert np.array_equal(got[s].view(np.uint32), twin[s].view(np.uint32)), "sparse path not bit exact"
         if flags.any():
             absdot = oracle.sddmm_f64(rows, K, ro, ci, np.abs(A), np.abs(B))
             err = np.abs(got[flags].astype(np.float64) - model[flags])
@@ -105,6 +118,9 @@ def test_other_k(engine, oracle, K):
 def test_large_k_sparse_without_lds(engine, oracle):
     rows, cols, ro, ci = synth.random_pattern(40, 50, 400, seed=99)
     check_case(engine, oracle, rows, cols, ro, ci, 2048, 0.3, 1.1, 0)
+    # hybrid at the same K: the residue reads the fp16 copies, A rows straight from memory
+    rows, cols, ro, ci = synth.community_graph(n=120, avg_degree=30, communities=3, seed=5)
+    check_case(engine, oracle, rows, cols, ro, ci, 2048, 0.2, 0.1, 0)
 
 
 @pytest.mark.parametrize("knobs", [
@@ -117,6 +133,7 @@ def test_large_k_sparse_without_lds(engine, oracle):
     {"BSMR_SPARSE_LPE": "4", "BSMR_SPARSE_ENTRIES_PER_WG": "32"}, {"BSMR_SPARSE_LPE": "16"},
     {"BSMR_OUTPUT_MODE": "0"}, {"BSMR_OUTPUT_MODE": "0", "BSMR_COLUMN_ORDER": "0"},
     {"BSMR_COLUMN_ORDER": "0"}, {"BSMR_OUTPUT_MODE": "0", "BSMR_DENSE_GROUP": "4"},
+    {"BSMR_SPARSE_LOWP": "0"}, {"BSMR_SPARSE_LOWP": "0", "BSMR_SPARSE_LPE": "4"},
     {"BSMR_OUTPUT_MODE": "2"}, {"BSMR_OUTPUT_MODE": "2", "BSMR_DENSE_GROUP": "4"},
     {"BSMR_OUTPUT_MODE": "2", "BSMR_DENSE_GROUP": "2", "BSMR_DENSE_BLOCKS_PER_WG": "7"},
     {"BSMR_DENSE_BLOCKS_PER_WG": "1"}, {"BSMR_DENSE_BLOCKS_PER_WG": "5", "BSMR_DENSE_GROUP": "2"},
@@ -128,7 +145,7 @@ def test_plan_knobs(engine, oracle, monkeypatch, knobs, K):
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     rows, cols, ro, ci = synth.community_graph(n=330, avg_degree=40, communities=6, seed=K)
-    lpe = int(knobs.get("BSMR_SPARSE_LPE", 8))
+    lpe = int(knobs["BSMR_SPARSE_LPE"]) if "BSMR_SPARSE_LPE" in knobs else None
     for delta in (0.0, 0.1):
         for mode in (0, 1):
             csr = engine.CSR.from_arrays(rows, cols, ro, ci)
@@ -138,8 +155,17 @@ def test_plan_knobs(engine, oracle, monkeypatch, knobs, K):
             got = run_hip(engine, pipe, K, A, B, mode)
             twin, flags, model = expected_twin(oracle, pipe, K, ro, ci, A, B, mode, lpe=lpe)
             s = ~flags
-            assert np.array_equal(got[s].view(np.uint32), twin[s].view(np.uint32))
             absdot = oracle.sddmm_f64(rows, K, ro, ci, np.abs(A), np.abs(B))
+            lowp_residue = bool(pipe.plan_stats()["sparse_lowp"])
+            if knobs.get("BSMR_SPARSE_LOWP") == "0" or knobs.get("BSMR_CONVERT_IN_KERNEL") == "1":
+                assert not lowp_residue
+            if knobs.get("BSMR_CONVERT_IN_KERNEL") == "0" and flags.any() and s.any():
+                assert lowp_residue
+            if lowp_residue:
+                err = np.abs(got[s].astype(np.float64) - model[s])
+                assert (err <= (K / 16 + 8) * 2.0 ** -23 * absdot[s]).all()
+            else:
+                assert np.array_equal(got[s].view(np.uint32), twin[s].view(np.uint32))
             err = np.abs(got[flags].astype(np.float64) - model[flags])
             assert (err <= (K / 32 + 4) * 2.0 ** -23 * absdot[flags]).all()
             if "BSMR_DENSE_GROUP" in knobs:
@@ -294,6 +320,30 @@ def test_nips_like_hybrid_k32(engine, oracle):
     """BASELINE configs[0] on the GPU: K=32, alpha=0.3, delta=0.3."""
     rows, cols, ro, ci = synth.nips_like()
     check_case(engine, oracle, rows, cols, ro, ci, 32, 0.3, 0.3, 0)
+
+
+@pytest.mark.parametrize("name,pattern,K,mode", [
+    ("mycielskian14", lambda: synth.mycielskian_pattern(14), 128, 0),
+    ("mycielskian14", lambda: synth.mycielskian_pattern(14), 32, 2),
+    ("wathen100", lambda: synth.wathen_pattern(100, 100), 128, 0),
+    ("Trefethen_20000", lambda: synth.trefethen_pattern(20000), 64, 0),
+])
+def test_suitesparse_patterns_match_reference_split_and_cpu(engine, oracle, name, pattern, K, mode):
+    """Real SuiteSparse inputs at the reference's default alpha = delta = 0.3: the device plan
+    is built from the same dense / sparse split the reference logged on its RTX 4090
+    (tests/golden/reference_logs.json), and the result meets the reference's acceptance test."""
+    import json
+    from pathlib import Path
+    golden = json.loads((Path(__file__).parent / "golden" / "reference_logs.json").read_text())["matrices"][name]
+    run = next(r for r in golden["runs"] if abs(r["alpha"] - 0.3) < 1e-6 and abs(r["delta"] - 0.3) < 1e-6)
+    rows, cols, ro, ci = pattern()
+    pipe = check_case(engine, oracle, rows, cols, ro, ci, K, 0.3, 0.3, mode)
+    st = pipe.plan_stats()
+    assert pipe.num_clusters == run["bsmr_numClusters"]
+    assert pipe.evaluate()["num_dense_blocks"] == run["bsmr_numDenseBlock"]
+    assert st["num_dense_blocks"] == int(pipe.array("blockOffsets")[-1])
+    assert st["num_dense_entries"] == run["bsmr_numDenseData"]
+    assert st["num_sparse_entries"] == run["bsmr_numSparseData"]
 
 
 def test_hipgraph_capture_and_replay(engine, oracle):
