@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "cluster_kernels.hpp"
 #include "plan_pack.hpp"
 #include "sddmm_kernels.hpp"
 
@@ -814,3 +816,184 @@ int bsmr_sddmm_host(bsmr_plan* plan, uint32_t K, const float* A_host, const floa
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Row clustering on the device (csrc/cluster_kernels.hpp)
+// ---------------------------------------------------------------------------
+namespace {
+
+// threads of the reference's clustering block (src/rowReordering.cu:912-922)
+uint32_t clusterThreads(size_t numBins) {
+    if (numBins < 32) return 32;
+    const uint32_t candidate = 32u * (uint32_t)std::ceil((float)(numBins / 4) / 32.0f);
+    return std::min<uint32_t>(1024, std::max<uint32_t>(32, candidate));
+}
+
+// warps whose partial reaches the result of the reference's fold (include/cudaUtil.cuh:37-43)
+uint32_t liveWarpMask(uint32_t T) {
+    const uint32_t W = T / 32u;
+    std::vector<uint32_t> members(W);
+    for (uint32_t w = 0; w < W; ++w) members[w] = 1u << w;
+    for (uint32_t s = T / 64u; s >= 1; s >>= 1)
+        for (uint32_t w = 0; w < s; ++w) members[w] |= members[w + s];
+    return members[0];
+}
+
+struct DeviceBuffers {
+    std::vector<void*> ptrs;
+    ~DeviceBuffers() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    bool alloc(T** out, size_t count, const char* what) {
+        void* p = nullptr;
+        if (!hipOk(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)), what)) return false;
+        ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return true;
+    }
+};
+
+}  // namespace
+
+extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const uint32_t* row_offsets,
+                                 const uint32_t* col_indices, uint32_t bin_width, float alpha,
+                                 uint32_t* reordered_rows, uint32_t* num_reordered, int32_t* num_clusters,
+                                 bsmr_cluster_stats* stats) {
+    if (!row_offsets || !reordered_rows || !num_reordered || !num_clusters || bin_width == 0)
+        return BSMR_ERR_INVALID_ARG;
+    *num_reordered = 0;
+    *num_clusters = 0;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (rows == 0) return BSMR_OK;
+    const uint32_t nnz = row_offsets[rows];
+    if (nnz && !col_indices) return BSMR_ERR_INVALID_ARG;
+    int st = useDevice(device);
+    if (st != BSMR_OK) return st;
+    try {
+        const size_t numBins = (size_t)std::ceil((float)cols / (float)bin_width);
+        const uint32_t T = clusterThreads(numBins);
+        const size_t tableBytes = (size_t)rows * numBins * sizeof(uint32_t);
+        size_t freeBytes = 0, totalBytes = 0;
+        BSMR_HIP(hipMemGetInfo(&freeBytes, &totalBytes));
+        // the rows x bins table has to fit beside the operands; the histogram of one row has to fit in LDS
+        if (tableBytes > freeBytes / 2 || numBins * sizeof(uint32_t) > 160u * 1024u - 64u) return BSMR_ERR_OOM;
+
+        hipEvent_t ev0, ev1;
+        BSMR_HIP(hipEventCreate(&ev0));
+        BSMR_HIP(hipEventCreate(&ev1));
+        struct EventGuard {
+            hipEvent_t a, b;
+            ~EventGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+        } guard{ev0, ev1};
+        hipStream_t s = nullptr;
+        BSMR_HIP(hipEventRecord(ev0, s));
+
+        DeviceBuffers dev;
+        const uint32_t live = liveWarpMask(T);
+        uint32_t *dRowOffsets, *dCols, *dTable, *dDisp, *dSquares, *dOrder, *dRep, *dCluster;
+        bsmr::ClusterState* dState;
+        if (!dev.alloc(&dRowOffsets, (size_t)rows + 1, "hipMalloc(rowOffsets)") ||
+            !dev.alloc(&dCols, nnz, "hipMalloc(colIndices)") || !dev.alloc(&dTable, (size_t)rows * numBins, "hipMalloc(table)") ||
+            !dev.alloc(&dDisp, rows, "hipMalloc(dispersion)") || !dev.alloc(&dSquares, rows, "hipMalloc(rowSquares)") ||
+            !dev.alloc(&dOrder, rows, "hipMalloc(order)") ||
+            !dev.alloc(&dRep, numBins, "hipMalloc(rep)") || !dev.alloc(&dCluster, rows, "hipMalloc(cluster)") ||
+            !dev.alloc(&dState, 1, "hipMalloc(state)"))
+            return BSMR_ERR_OOM;
+        BSMR_HIP(hipMemcpyAsync(dRowOffsets, row_offsets, ((size_t)rows + 1) * 4, hipMemcpyHostToDevice, s));
+        if (nnz) BSMR_HIP(hipMemcpyAsync(dCols, col_indices, (size_t)nnz * 4, hipMemcpyHostToDevice, s));
+        BSMR_HIP(hipMemsetAsync(dTable, 0, std::max<size_t>(tableBytes, 16), s));
+
+        // 1. histograms + dispersion scores
+        const size_t histLds = numBins * sizeof(uint32_t);
+        if (histLds > 64 * 1024)
+            BSMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bsmr::clusterHistogram),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)histLds));
+        hipLaunchKernelGGL(bsmr::clusterHistogram, dim3(rows), dim3(256), histLds, s, dRowOffsets, dCols,
+                           (uint32_t)numBins, bin_width, T, live, dTable, dDisp, dSquares);
+        BSMR_HIP(hipGetLastError());
+        std::vector<uint32_t> disp(rows);
+        BSMR_HIP(hipMemcpyAsync(disp.data(), dDisp, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+        BSMR_HIP(hipStreamSynchronize(s));
+
+        // 2. ascending dispersion, ties in ascending row id (src/rowReordering.cu:1056-1062)
+        std::vector<uint32_t> order(rows);
+        for (uint32_t r = 0; r < rows; ++r) order[r] = r;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return disp[a] < disp[b]; });
+        uint32_t firstNonEmpty = 0;
+        while (firstNonEmpty < rows && disp[order[firstNonEmpty]] == 0) ++firstNonEmpty;
+
+        // 3. clusters
+        std::vector<uint32_t> cluster(rows, bsmr::kNoCluster);
+        for (uint32_t p = 0; p < firstNonEmpty; ++p) cluster[p] = 0;
+        bsmr::ClusterState state{};
+        // G workgroups per pass, each judging every G-th position of the pass's chunk
+        const uint32_t grid = (uint32_t)std::max(32, std::min(envInt("BSMR_CLUSTER_GRID", 512), 65535));
+        const uint32_t maxChunk = std::max<uint32_t>(
+            bsmr::kClusterMinChunk, (uint32_t)std::min(envInt("BSMR_CLUSTER_CHUNK", (int)(32 * grid)), 1 << 24));
+        if (firstNonEmpty < rows) {
+            cluster[firstNonEmpty] = 1;
+            state.seed = firstNonEmpty;
+            state.cursor = firstNonEmpty + 1;
+            state.chunk = 2 * bsmr::kClusterMinChunk;
+            state.clusterId = 1;
+            state.firstHit = bsmr::kNoCluster;
+            state.done = firstNonEmpty + 1 >= rows ? 1u : 0u;
+            BSMR_HIP(hipMemcpyAsync(dOrder, order.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
+            BSMR_HIP(hipMemcpyAsync(dCluster, cluster.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
+            BSMR_HIP(hipMemcpyAsync(dRep, dTable + (size_t)order[firstNonEmpty] * numBins, numBins * 4,
+                                    hipMemcpyDeviceToDevice, s));
+            BSMR_HIP(hipMemcpyAsync(dState, &state, sizeof(state), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(bsmr::clusterInitSquares, dim3(1), dim3(T), 0, s, dRep, (uint32_t)numBins, live, dState);
+            // every pass is a no-op once `done` is set, so passes are enqueued in batches and the
+            // flag is read between batches; at most one pass per row plus the empty stretches
+            const uint64_t passLimit = 4ull * rows + 64;
+            uint64_t enqueued = 0;
+            while (!state.done) {
+                if (enqueued > passLimit * 64) return BSMR_ERR_HIP;  // cannot happen: every pass advances the cursor
+                for (int i = 0; i < 256; ++i)
+                    hipLaunchKernelGGL(bsmr::clusterPass, dim3(grid), dim3(T), 0, s, dTable, dSquares, dOrder, rows,
+                                       (uint32_t)numBins, alpha, maxChunk, live, dRep, dCluster, dState);
+                enqueued += 256;
+                BSMR_HIP(hipGetLastError());
+                BSMR_HIP(hipMemcpyAsync(&state, dState, sizeof(state), hipMemcpyDeviceToHost, s));
+                BSMR_HIP(hipStreamSynchronize(s));
+            }
+            BSMR_HIP(hipMemcpyAsync(cluster.data(), dCluster, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+            BSMR_HIP(hipStreamSynchronize(s));
+        }
+        BSMR_HIP(hipEventRecord(ev1, s));
+        BSMR_HIP(hipEventSynchronize(ev1));
+
+        // 4. stable sort of the positions by cluster id, logged count, empty rows dropped
+        //    (src/rowReordering.cu:985-992, :1082-1090)
+        std::vector<uint32_t> positions(rows);
+        for (uint32_t p = 0; p < rows; ++p) positions[p] = p;
+        std::stable_sort(positions.begin(), positions.end(),
+                         [&](uint32_t a, uint32_t b) { return cluster[a] < cluster[b]; });
+        *num_clusters = (int32_t)cluster[positions[positions[rows - 1]]] + (firstNonEmpty != 0 ? 1 : 0);
+        uint32_t out = 0;
+        bool leading = true;
+        for (uint32_t i = 0; i < rows; ++i) {
+            const uint32_t row = order[positions[i]];
+            if (leading && row_offsets[row + 1] == row_offsets[row]) continue;
+            leading = false;
+            reordered_rows[out++] = row;
+        }
+        *num_reordered = out;
+        if (stats) {
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, ev0, ev1);
+            stats->elapsed_ms = ms;
+            stats->passes = state.passes;
+            stats->similarities = state.judged;
+            stats->threads_per_pair = T;
+            stats->table_bytes = tableBytes;
+        }
+        return BSMR_OK;
+    } catch (const std::bad_alloc&) {
+        return BSMR_ERR_OOM;
+    } catch (...) {
+        return BSMR_ERR_INVALID_ARG;
+    }
+}

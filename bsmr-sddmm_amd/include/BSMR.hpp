@@ -159,6 +159,26 @@ UIN calculateBlockSize(const sparseMatrix::CSR<float>& matrix, size_t freeDevice
 // BSA row clustering (reference bsa_rowReordering_gpu, src/rowReordering.cu:1027-1095,
 // whose mutex pipeline is equivalent to finishing cluster c before c+1 starts).
 // Host implementation over sparse histograms with an inverted bin index.
+// Where BSMR::rowReordering runs the clustering.  The reference always uses the GPU
+// (bsa_rowReordering_gpu); both implementations here give the same row order and cluster
+// count, so this is a matter of speed only.
+//   -2 (default): device 0 when one is present and the rows are long enough for the dense
+//                 device scan to win (>= 32 stored entries per non-empty row on average;
+//                 measured on MI355X: mycielskian15 0.33 s on the device against 5-12 s on
+//                 the host, wathen100 0.79 s against 0.24 s); environment BSMR_CLUSTER =
+//                 host | device overrides the rule
+//   -1          : host
+//   >= 0        : that device (falls back to the host when the table does not fit)
+void setClusteringDevice(int device);
+int clusteringDevice();
+
+// bsa_rowReordering_gpu of the reference (src/rowReordering.cu:1027-1095) on the MI355X:
+// csrc/cluster_kernels.hpp through bsmr_cluster_rows.  Returns false when the device path is
+// unavailable (no device, table too large); the outputs are then untouched.
+bool bsa_rowReordering_device(const sparseMatrix::CSR<float>& matrix, const float alpha, const UIN block_size,
+                              int device, std::vector<UIN>& reorderedRows, int& num_clusters,
+                              float& reordering_time);
+
 std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, const float alpha,
                                         const UIN block_size, int& num_clusters,
                                         float& reordering_time);

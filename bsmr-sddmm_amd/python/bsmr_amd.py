@@ -61,6 +61,11 @@ class ReorderingReport(C.Structure):
                 ("max_dense_blocks_per_panel", C.c_uint32), ("max_sparse_blocks_per_panel", C.c_uint32)]
 
 
+class ClusterStats(C.Structure):
+    _fields_ = [("elapsed_ms", C.c_float), ("passes", C.c_uint32), ("similarities", C.c_uint32),
+                ("threads_per_pair", C.c_uint32), ("table_bytes", C.c_uint64)]
+
+
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("convert_ms", C.c_float), ("dense_ms", C.c_float),
                 ("sparse_ms", C.c_float)]
@@ -82,6 +87,8 @@ HIP_SYMBOLS = {
     "bsmr_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RphmDesc)]),
     "bsmr_plan_destroy": (C.c_int, [C.c_void_p]),
     "bsmr_plan_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
+    "bsmr_cluster_rows": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float,
+                                    C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p]),
     "bsmr_plan_sparse_choice": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32),
                                           C.POINTER(C.c_uint32)]),
     "bsmr_plan_dense_choice": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
@@ -325,6 +332,17 @@ class Pipeline:
         g, t, u = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
         _check(hip().bsmr_plan_dense_choice(self.plan, K, C.byref(g), C.byref(t), C.byref(u)), "dense_choice")
         return {"group_size": g.value, "tiles": t.value, "union_columns": u.value}
+
+
+def cluster_rows_device(rows, cols, row_offsets, col_indices, bin_width, alpha, device=0):
+    """bsmr_cluster_rows: (status, reorderedRows, numClusters, stats) - the row clustering on the GPU"""
+    ro = np.ascontiguousarray(row_offsets, dtype=np.uint32)
+    ci = np.ascontiguousarray(col_indices, dtype=np.uint32)
+    out = np.zeros(max(rows, 1), dtype=np.uint32)
+    n, clusters, stats = C.c_uint32(0), C.c_int32(0), ClusterStats()
+    st = hip().bsmr_cluster_rows(device, rows, cols, _ptr(ro), _ptr(ci), bin_width, alpha, _ptr(out),
+                                 C.byref(n), C.byref(clusters), C.byref(stats))
+    return st, out[:n.value].copy(), clusters.value, {k: getattr(stats, k) for k, _ in ClusterStats._fields_}
 
 
 def sddmm_cpu(csr: CSR, K: int, A: np.ndarray, B: np.ndarray) -> np.ndarray:

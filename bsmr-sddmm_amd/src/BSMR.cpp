@@ -9,6 +9,9 @@
 // searches, and reformulates both statistics passes from
 // O(panels x blocks x nnz_panel) to O(nnz log nnz).
 
+#include <cstdlib>
+#include <string>
+
 #include "BSMR.hpp"
 
 #include <algorithm>
@@ -72,7 +75,20 @@ void BSMR::rowReordering(const float similarityThreshold, const sparseMatrix::CS
     float total = 0.0f;
     for (int i = 0; i < iters; ++i) {
         float once = 0.0f;
-        reorderedRows_ = bsa_rowReordering_host(matrix, similarityThreshold, blockSize, numClusters_, once);
+        int device = clusteringDevice();
+        if (device == -2) {  // automatic
+            const char* env = std::getenv("BSMR_CLUSTER");
+            const std::string choice = env ? env : "";
+            int count = 0;
+            const bool present = choice != "host" && bsmr_device_count(&count) == BSMR_OK && count > 0;
+            UIN nonEmpty = 0;
+            for (UIN r = 0; r < matrix.row(); ++r) nonEmpty += matrix.rowOffsets()[r + 1] > matrix.rowOffsets()[r];
+            const bool longRows = nonEmpty && matrix.nnz() / nonEmpty >= 32;
+            device = present && (choice == "device" || longRows) ? 0 : -1;
+        }
+        if (device < 0 ||
+            !bsa_rowReordering_device(matrix, similarityThreshold, blockSize, device, reorderedRows_, numClusters_, once))
+            reorderedRows_ = bsa_rowReordering_host(matrix, similarityThreshold, blockSize, numClusters_, once);
         total += once;
     }
     rowReorderingTime_ = total / iters;

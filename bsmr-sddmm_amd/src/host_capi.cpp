@@ -93,12 +93,17 @@ bsmr_pipeline* bsmr_pipeline_create(const bsmr_csr* m, float alpha, float delta,
         } else if (block_size != 0) {
             int clusters = 0;
             float t = 0;
-            std::vector<UIN> rows = bsa_rowReordering_host(m->m, alpha, block_size, clusters, t);
+            std::vector<UIN> rows;
+            if (device < 0 || !bsa_rowReordering_device(m->m, alpha, block_size, device, rows, clusters, t))
+                rows = bsa_rowReordering_host(m->m, alpha, block_size, clusters, t);
             if (rows.empty()) return nullptr;
             p->clusters = clusters;
             p->bsmr.colReordering(delta, m->m, rows);
         } else {
+            const int before = clusteringDevice();
+            if (device < 0) setClusteringDevice(-1);  // host-only pipeline: no GPU touched
             p->bsmr = BSMR(alpha, delta, m->m, 1);
+            setClusteringDevice(before);
         }
         p->rphm.reset(new RPHM(m->m, p->bsmr, device));
         return p.release();

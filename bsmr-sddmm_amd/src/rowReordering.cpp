@@ -356,7 +356,9 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
     }
 
     Representative rep(blockSum, numBins);
-    const int maxThreads = omp_get_max_threads();
+    // one short parallel region per chunk: beyond ~16 threads the barriers cost more than the
+    // similarities (measured: a 128-thread box ran this 2-3x slower than an 8-thread one)
+    const int maxThreads = std::min(omp_get_max_threads(), 16);
     std::vector<PairScratch> scratch;
     scratch.reserve(maxThreads);
     for (int t = 0; t < maxThreads; ++t) scratch.emplace_back(numBins, blockSum.nodes());
@@ -408,7 +410,7 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
             while (i < pending.size()) {
                 const size_t n = std::min(kChunk, pending.size() - i);
                 long long firstHit = static_cast<long long>(n);
-#pragma omp parallel for schedule(static) reduction(min : firstHit) if (n >= 64)
+#pragma omp parallel for schedule(static) reduction(min : firstHit) num_threads(maxThreads) if (n >= 64)
                 for (long long j = 0; j < static_cast<long long>(n); ++j) {
                     const UIN row = order[pending[i + j]];
                     if (similarity(rep, enc.begin(row), enc.end(row), enc.squares[row],
@@ -476,4 +478,31 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
     }
     reordering_time = msSince(t0);
     return permutation;
+}
+
+// ---------------------------------------------------------------------------
+// device path
+// ---------------------------------------------------------------------------
+namespace {
+int g_clusteringDevice = -2;
+}
+void setClusteringDevice(int device) { g_clusteringDevice = device; }
+int clusteringDevice() { return g_clusteringDevice; }
+
+bool bsa_rowReordering_device(const sparseMatrix::CSR<float>& matrix, const float alpha, const UIN block_size,
+                              int device, std::vector<UIN>& reorderedRows, int& num_clusters,
+                              float& reordering_time) {
+    const auto t0 = Clock::now();
+    std::vector<UIN> rows(matrix.row());
+    uint32_t count = 0;
+    int32_t clusters = 0;
+    const int st = bsmr_cluster_rows(device, matrix.row(), matrix.col(), matrix.rowOffsets().data(),
+                                     matrix.colIndices().data(), block_size == 0 ? 16 : block_size, alpha,
+                                     rows.data(), &count, &clusters, nullptr);
+    if (st != BSMR_OK) return false;
+    rows.resize(count);
+    reorderedRows.swap(rows);
+    num_clusters = clusters;
+    reordering_time = msSince(t0);
+    return true;
 }

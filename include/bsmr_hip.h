@@ -125,6 +125,26 @@ int bsmr_plan_get_stats(const bsmr_plan *plan, bsmr_plan_stats *out);
 int bsmr_plan_dense_choice(const bsmr_plan *plan, uint32_t K, uint32_t *group_size,
                            uint64_t *tiles, uint64_t *union_columns);
 
+/* Row clustering of the BSMR pipeline on the device: bsa_rowReordering_gpu
+ * (src/rowReordering.cu:1027-1095 = calculateDispersion :478-501 + get_permutation_gpu
+ * :893-1007 + the removal of empty rows :1082-1090).  S as host CSR; reordered_rows has
+ * room for `rows` ids and receives the non-empty rows in clustered order; num_clusters is
+ * the value the reference logs as bsmr_numClusters.  Results are identical to the host
+ * implementation behind BSMR::rowReordering.  BSMR_ERR_OOM: the rows x bins table does not
+ * fit in half of the free device memory (or one row's histogram does not fit in LDS) - the
+ * caller falls back to the host implementation. */
+typedef struct bsmr_cluster_stats {
+    float    elapsed_ms;        /* device time, uploads and downloads included        */
+    uint32_t passes;            /* speculative passes launched that did work          */
+    uint32_t similarities;      /* (representative, row) pairs evaluated              */
+    uint32_t threads_per_pair;  /* workgroup size = the reference's clustering block  */
+    uint64_t table_bytes;       /* rows x bins histogram table                        */
+} bsmr_cluster_stats;
+int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const uint32_t *row_offsets,
+                      const uint32_t *col_indices, uint32_t bin_width, float alpha,
+                      uint32_t *reordered_rows, uint32_t *num_reordered, int32_t *num_clusters,
+                      bsmr_cluster_stats *stats);
+
 /* How the sparse residue of a call (K, compute_mode) will run: lanes that share one entry's
  * K-long dot product (the fp32 summation order of the residue depends on it; the CPU twin in
  * oracle/sddmm_oracle.c takes the same number) and whether it reads the fp16/bf16 copies. */

@@ -198,9 +198,11 @@ int oracle_bsa_row_reordering(uint32_t rows, uint32_t cols, const uint32_t* rowO
     for (uint32_t p = 0; p < rows; ++p) cluster[p] = NULL_CLUSTER;
     while (zeroRows < rows && byDisp[zeroRows].key == 0) cluster[zeroRows++] = 0;
 
+    /* one short parallel region per scan step: more than a few threads only adds barrier time
+     * (and on a CPU-quota-limited box the spinning workers starve each other) */
     int maxThreads = 1;
 #ifdef _OPENMP
-    maxThreads = omp_get_max_threads();
+    maxThreads = omp_get_max_threads() < 8 ? omp_get_max_threads() : 8;
 #endif
     void* scratch = malloc((size_t)maxThreads * 2u * T * sizeof(uint32_t));
     enum { CHUNK = 256 };
@@ -216,7 +218,7 @@ int oracle_bsa_row_reordering(uint32_t rows, uint32_t cols, const uint32_t* rowO
         while (i < np) {
             const size_t n = np - i < CHUNK ? np - i : CHUNK;
             long long firstHit = (long long)n;
-#pragma omp parallel for schedule(static) reduction(min : firstHit)
+#pragma omp parallel for schedule(static) reduction(min : firstHit) num_threads(maxThreads)
             for (long long j = 0; j < (long long)n; ++j) {
                 int tid = 0;
 #ifdef _OPENMP

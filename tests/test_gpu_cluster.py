@@ -1,0 +1,87 @@
+"""Row clustering on the device (bsmr_cluster_rows) against the host implementation, the
+plain dense restatement and the reference's published logs - identical row order and cluster
+count everywhere."""
+import json
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import synth
+from test_clustering_exact import CASES, clustered_pattern
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = json.loads((Path(__file__).parent / "golden" / "reference_logs.json").read_text())["matrices"]
+
+
+def logged_clusters(name, alpha):
+    return next(r["bsmr_numClusters"] for r in GOLDEN[name]["runs"] if abs(r["alpha"] - alpha) < 1e-6)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"bins{-(-c[1] // c[2])}" for c in CASES])
+@pytest.mark.parametrize("alpha", [0.1, 0.3, 0.6, 0.9])
+def test_device_order_equals_host_and_oracle(engine, oracle, case, alpha):
+    rows, cols, bw, groups, per_row, seed = case
+    rows, cols, ro, ci = clustered_pattern(rows, cols, groups, per_row, seed)
+    st, perm, clusters, stats = engine.cluster_rows_device(rows, cols, ro, ci, bw, alpha)
+    assert st == engine.OK
+    want, want_clusters = oracle.bsa_row_reordering(rows, cols, ro, ci, bw, alpha)
+    assert np.array_equal(perm, want) and clusters == want_clusters
+    pipe = engine.Pipeline(engine.CSR.from_arrays(rows, cols, ro, ci), alpha=alpha, delta=0.3, block_size=bw,
+                           device=-1)
+    assert np.array_equal(pipe.array("reorderedRows"), perm)
+    assert stats["threads_per_pair"] == oracle.lib.oracle_cluster_threads(-(-cols // bw))
+
+
+@pytest.mark.parametrize("alpha", [-0.5, 0.0, 0.3, 1.0, 1.5])
+def test_device_edge_cases(engine, oracle, alpha):
+    """empty rows, rows hidden in skipped bins, alphas outside (0, 1), a single row, no rows"""
+    rng = np.random.default_rng(11)
+    cols, bw = 4800, 16
+    hidden_bins = [b for b in range(300) if (b % 96) >= 64]
+    per = []
+    for r in range(90):
+        if r % 3 == 0:
+            bins = rng.choice(hidden_bins, size=4, replace=False)
+        elif r % 3 == 1:
+            bins = np.concatenate([rng.choice(hidden_bins, size=2, replace=False), rng.integers(0, 64, 3)])
+        else:
+            bins = rng.integers(0, 64, 5)
+        per.append(np.unique(bins * bw + rng.integers(0, bw, bins.size)))
+    per[7] = np.zeros(0, np.int64)
+    per[8] = np.zeros(0, np.int64)
+    ro = np.zeros(len(per) + 1, dtype=np.uint32)
+    ro[1:] = np.cumsum([c.size for c in per])
+    ci = np.concatenate(per).astype(np.uint32)
+    st, perm, clusters, _ = engine.cluster_rows_device(len(per), cols, ro, ci, bw, alpha)
+    want, want_clusters = oracle.bsa_row_reordering(len(per), cols, ro, ci, bw, alpha)
+    assert st == engine.OK and np.array_equal(perm, want) and clusters == want_clusters
+    # one row / all rows empty
+    st, perm, clusters, _ = engine.cluster_rows_device(1, 40, np.array([0, 2], np.uint32), np.array([3, 9], np.uint32), 16, alpha)
+    assert st == engine.OK and perm.tolist() == [0] and clusters == 1
+    st, perm, clusters, _ = engine.cluster_rows_device(3, 40, np.zeros(4, np.uint32), np.zeros(0, np.uint32), 16, alpha)
+    assert st == engine.OK and perm.size == 0
+
+
+@pytest.mark.parametrize("name,pattern,alphas", [
+    ("mycielskian14", lambda: synth.mycielskian_pattern(14), (0.1, 0.3, 0.5, 0.7, 0.9)),
+    ("Trefethen_20000", lambda: synth.trefethen_pattern(20000), (0.1, 0.3, 0.5, 0.7, 0.9)),
+    ("wathen100", lambda: synth.wathen_pattern(100, 100), (0.3, 0.9)),
+    ("mycielskian15", lambda: synth.mycielskian_pattern(15), (0.3,)),
+])
+def test_device_clustering_reproduces_reference_logs(engine, name, pattern, alphas):
+    rows, cols, ro, ci = pattern()
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    for alpha in alphas:
+        t0 = time.perf_counter()
+        st, perm, clusters, stats = engine.cluster_rows_device(rows, cols, ro, ci, 16, alpha)
+        wall = time.perf_counter() - t0
+        assert st == engine.OK
+        assert clusters == logged_clusters(name, alpha), (name, alpha)
+        print(f"{name} alpha={alpha}: {clusters} clusters, device {stats['elapsed_ms']:.1f} ms (wall {wall * 1e3:.0f} ms), "
+              f"{stats['passes']} passes, {stats['similarities']} similarities")
+        if alpha == 0.3:
+            pipe = engine.Pipeline(csr, alpha=alpha, delta=0.3, block_size=16, device=-1)
+            assert np.array_equal(pipe.array("reorderedRows"), perm)
