@@ -31,9 +31,9 @@ out = {"bench": {k: bench[k] for k in ("value", "ms_per_step", "kernels_ms", "ro
 # HBM traffic of the dominant kernel, per launch: FETCH_SIZE / WRITE_SIZE are in KiB; gfx950
 # FETCH_SIZE counts half of a 16-B-per-lane stream (MI355X_MICROARCH.md "HBM"), so it is doubled.
 dom = bench["roofline"]["kernel"]
-name = {"dense": "denseGroups", "sparse": "sparseEntries", "convert": "convertOperands"}[dom]
+names = {"dense": ("denseStream", "denseGroups"), "sparse": ("sparseEntries",), "convert": ("convertOperands",)}[dom]
 for k, c in pmc.items():
-    if name in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    if any(n in k for n in names) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         traffic = int((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
         out["traffic_bytes_per_launch"] = traffic
         tfile = dst / "traffic.json"
