@@ -891,13 +891,13 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
 
         DeviceBuffers dev;
         const uint32_t live = liveWarpMask(T);
-        uint32_t *dRowOffsets, *dCols, *dTable, *dDisp, *dSquares, *dOrder, *dRep, *dCluster;
+        uint32_t *dRowOffsets, *dCols, *dTable, *dDisp, *dSquares, *dOrder, *dCluster;
         bsmr::ClusterState* dState;
         if (!dev.alloc(&dRowOffsets, (size_t)rows + 1, "hipMalloc(rowOffsets)") ||
             !dev.alloc(&dCols, nnz, "hipMalloc(colIndices)") || !dev.alloc(&dTable, (size_t)rows * numBins, "hipMalloc(table)") ||
             !dev.alloc(&dDisp, rows, "hipMalloc(dispersion)") || !dev.alloc(&dSquares, rows, "hipMalloc(rowSquares)") ||
             !dev.alloc(&dOrder, rows, "hipMalloc(order)") ||
-            !dev.alloc(&dRep, numBins, "hipMalloc(rep)") || !dev.alloc(&dCluster, rows, "hipMalloc(cluster)") ||
+            !dev.alloc(&dCluster, rows, "hipMalloc(cluster)") ||
             !dev.alloc(&dState, 1, "hipMalloc(state)"))
             return BSMR_ERR_OOM;
         BSMR_HIP(hipMemcpyAsync(dRowOffsets, row_offsets, ((size_t)rows + 1) * 4, hipMemcpyHostToDevice, s));
@@ -927,34 +927,47 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
         std::vector<uint32_t> cluster(rows, bsmr::kNoCluster);
         for (uint32_t p = 0; p < firstNonEmpty; ++p) cluster[p] = 0;
         bsmr::ClusterState state{};
-        // G workgroups per pass, each judging every G-th position of the pass's chunk
+        // G workgroups per pass, each judging every G-th item of the pass; up to `active` clusters in flight
         const uint32_t grid = (uint32_t)std::max(32, std::min(envInt("BSMR_CLUSTER_GRID", 512), 65535));
         const uint32_t maxChunk = std::max<uint32_t>(
             bsmr::kClusterMinChunk, (uint32_t)std::min(envInt("BSMR_CLUSTER_CHUNK", (int)(32 * grid)), 1 << 24));
+        const uint32_t active = (uint32_t)std::max(1, std::min(envInt("BSMR_CLUSTER_ACTIVE", (int)bsmr::kClusterMaxActive),
+                                                               (int)bsmr::kClusterMaxActive));
         if (firstNonEmpty < rows) {
+            uint32_t* dReps;
+            if (!dev.alloc(&dReps, (size_t)active * numBins, "hipMalloc(representatives)")) return BSMR_ERR_OOM;
             cluster[firstNonEmpty] = 1;
-            state.seed = firstNonEmpty;
-            state.cursor = firstNonEmpty + 1;
-            state.chunk = 2 * bsmr::kClusterMinChunk;
-            state.clusterId = 1;
-            state.firstHit = bsmr::kNoCluster;
+            state.numActive = 1;
+            state.nextId = 1;
+            state.floor = firstNonEmpty;
+            state.freeReps = (active >= 32 ? 0xFFFFFFFFu : (1u << active) - 1u) & ~1u;
             state.done = firstNonEmpty + 1 >= rows ? 1u : 0u;
+            state.slot[0].seed = firstNonEmpty;
+            state.slot[0].cursor = firstNonEmpty + 1;
+            state.slot[0].chunk = 2 * bsmr::kClusterMinChunk;
+            state.slot[0].id = 1;
+            state.slot[0].firstHit = bsmr::kNoCluster;
+            state.slot[0].scan = firstNonEmpty + 1;
+            state.slot[0].rep = 0;
             BSMR_HIP(hipMemcpyAsync(dOrder, order.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
             BSMR_HIP(hipMemcpyAsync(dCluster, cluster.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
-            BSMR_HIP(hipMemcpyAsync(dRep, dTable + (size_t)order[firstNonEmpty] * numBins, numBins * 4,
+            BSMR_HIP(hipMemcpyAsync(dReps, dTable + (size_t)order[firstNonEmpty] * numBins, numBins * 4,
                                     hipMemcpyDeviceToDevice, s));
             BSMR_HIP(hipMemcpyAsync(dState, &state, sizeof(state), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(bsmr::clusterInitSquares, dim3(1), dim3(T), 0, s, dRep, (uint32_t)numBins, live, dState);
+            hipLaunchKernelGGL(bsmr::clusterInitSquares, dim3(1), dim3(T), 0, s, dReps, (uint32_t)numBins, live, dState);
             // every pass is a no-op once `done` is set, so passes are enqueued in batches and the
-            // flag is read between batches; at most one pass per row plus the empty stretches
-            const uint64_t passLimit = 4ull * rows + 64;
+            // flag is read between batches; a pass that does work advances at least one cursor
+            const uint64_t passLimit = 64ull * rows + 4096;
             uint64_t enqueued = 0;
             while (!state.done) {
-                if (enqueued > passLimit * 64) return BSMR_ERR_HIP;  // cannot happen: every pass advances the cursor
-                for (int i = 0; i < 256; ++i)
+                if (enqueued > passLimit) {
+                    g_lastHipError = "bsmr_cluster_rows: pass limit reached";
+                    return BSMR_ERR_HIP;
+                }
+                for (int i = 0; i < 128; ++i)
                     hipLaunchKernelGGL(bsmr::clusterPass, dim3(grid), dim3(T), 0, s, dTable, dSquares, dOrder, rows,
-                                       (uint32_t)numBins, alpha, maxChunk, live, dRep, dCluster, dState);
-                enqueued += 256;
+                                       (uint32_t)numBins, alpha, maxChunk, active, live, dReps, dCluster, dState);
+                enqueued += 128;
                 BSMR_HIP(hipGetLastError());
                 BSMR_HIP(hipMemcpyAsync(&state, dState, sizeof(state), hipMemcpyDeviceToHost, s));
                 BSMR_HIP(hipStreamSynchronize(s));

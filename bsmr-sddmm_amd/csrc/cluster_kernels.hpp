@@ -11,14 +11,19 @@
 // three implementations agree bit for bit (tests/test_gpu_cluster.py).
 //
 // How it is scheduled is different.  The reference chains one single-block kernel per cluster
-// through device-side launches and per-row mutexes; gfx950 has no device-side launch.  Here the
-// scan of a cluster is speculative: one pass judges the next `chunk` unassigned positions
-// against the current representative in parallel (one workgroup each), the smallest accepted
-// position wins (atomicMin), and the last workgroup to finish merges that row into the
-// representative and moves the cursor behind it - everything before it was judged with the
-// right representative, everything after it is judged again by the next pass.  The chunk
-// adapts to the distance between hits.  All state lives in device memory, so the host only
-// enqueues passes and polls a flag; a pass that finds the work finished is a no-op.
+// through device-side launches and per-row mutexes; gfx950 has no device-side launch.  Here:
+//   * Several clusters are in flight, oldest first.  Cluster j+1 is seeded by the first row
+//     cluster j passed over and only ever judges positions cluster j has already decided
+//     (cursor[j+1] <= cursor[j]) - the hand-over-hand order of the reference's mutexes, so every
+//     row meets the clusters in the same order and the same state as in a sequential run.
+//   * The scan of each cluster is speculative: one pass judges the next `chunk` unassigned
+//     positions of every active cluster against that cluster's representative in parallel (one
+//     workgroup per pair), the smallest accepted position of a cluster wins (atomicMin), and the
+//     last workgroup to finish merges those rows, moves each cursor behind its hit - everything
+//     before it was judged with the right representative, everything after it is judged again -
+//     adapts the chunks, retires finished clusters and seeds the next one.
+// All state lives in device memory, so the host only enqueues passes and polls a flag; a pass
+// that finds the work finished is a no-op.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -29,17 +34,29 @@ namespace bsmr {
 constexpr uint32_t kNoCluster = 0xFFFFFFFFu;
 constexpr uint32_t kClusterMinChunk = 32;
 
+constexpr uint32_t kClusterMaxActive = 16;
+
+struct ClusterSlot {
+    uint32_t seed;      // position of the cluster's first row
+    uint32_t cursor;    // next position to judge
+    uint32_t chunk;     // positions judged by the next pass
+    uint32_t id;        // cluster id (1-based; 0 = empty rows)
+    uint32_t sq;        // representative's sum of squares over the bins that count (mod 2^32)
+    uint32_t firstHit;  // smallest accepted position of the running pass
+    uint32_t scan;      // positions in [seed + 1, scan) are assigned (search for the successor's seed)
+    uint32_t rep;       // which representative buffer the cluster owns
+};
+
 struct ClusterState {
-    uint32_t seed;       // position of the current cluster's first row
-    uint32_t cursor;     // next position to judge
-    uint32_t chunk;      // positions judged by the next pass
-    uint32_t clusterId;  // id of the current cluster (1-based; 0 = empty rows)
-    uint32_t firstHit;   // smallest accepted position of the running pass
+    uint32_t numActive;  // slots [0, numActive), oldest first
+    uint32_t nextId;     // id of the youngest cluster
+    uint32_t floor;      // every position below is assigned
+    uint32_t freeReps;   // bit r = representative buffer r is free
     uint32_t arrived;    // workgroups of the running pass that have finished
     uint32_t done;       // every row has a cluster
-    uint32_t sqRep;      // representative's sum of squares over the bins that count (mod 2^32)
     uint32_t passes;     // statistics
     uint32_t judged;     // statistics: similarities evaluated
+    ClusterSlot slot[kClusterMaxActive];
 };
 
 // does bin b take part in the reference's block-wide sums?  liveWarps: bit w = warp w reaches the
@@ -136,38 +153,59 @@ __device__ __forceinline__ float similarityAsReference(const uint32_t* __restric
     return minSum / maxSum;
 }
 
-// One speculative pass (see the header comment).  Workgroup g judges positions cursor + g,
-// cursor + g + G, ... (G = gridDim.x) of the pass's `chunk` and stops once an earlier position
-// has been accepted; block = T threads.
+// One speculative pass (see the header comment).  The positions to judge of all active clusters
+// form one list; workgroup g takes items g, g + G, ... (G = gridDim.x) and skips an item once an
+// earlier position of the same cluster has been accepted; block = T threads.
 __global__ void clusterPass(const uint32_t* __restrict__ table, const uint32_t* __restrict__ rowSquares,
                             const uint32_t* __restrict__ order, uint32_t rows, uint32_t numBins, float alpha,
-                            uint32_t maxChunk, uint32_t liveWarps, uint32_t* __restrict__ rep,
+                            uint32_t maxChunk, uint32_t maxActive, uint32_t liveWarps, uint32_t* __restrict__ reps,
                             uint32_t* __restrict__ cluster, ClusterState* __restrict__ state) {
     __shared__ float shmA[32], shmB[32];
     __shared__ uint32_t shared[3];
-    if (state->done) return;  // uniform over the grid: `done` only changes at the end of a pass
-    const uint32_t cursor = state->cursor, chunk = state->chunk, id = state->clusterId, seed = state->seed;
-    const uint32_t sqRep = state->sqRep;
-    if (blockIdx.x >= chunk) return;  // nothing to judge, and nobody waits for this workgroup
-    const uint32_t participants = chunk < gridDim.x ? chunk : gridDim.x;
+    __shared__ uint32_t sCursor[kClusterMaxActive], sLen[kClusterMaxActive], sStart[kClusterMaxActive + 1];
+    __shared__ uint32_t sHit[kClusterMaxActive];
+    __shared__ ClusterSlot sSlot[kClusterMaxActive + 1];
+    if (state->done) return;  // uniform over the grid: the state only changes at the end of a pass
+    const uint32_t active = state->numActive;
+    if (threadIdx.x < active) sSlot[threadIdx.x] = state->slot[threadIdx.x];  // one slot per lane: one round trip
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t j = 0; j < active; ++j) {
+            const ClusterSlot& c = sSlot[j];
+            // a younger cluster only judges what the next older one has already decided
+            const uint32_t limit = j == 0 ? rows : sSlot[j - 1].cursor;
+            const uint32_t len = c.cursor < limit ? (c.chunk < limit - c.cursor ? c.chunk : limit - c.cursor) : 0u;
+            sCursor[j] = c.cursor;
+            sLen[j] = len;
+            sStart[j] = total;
+            total += len;
+        }
+        sStart[active] = total;
+    }
+    __syncthreads();
+    const uint32_t total = sStart[active];
+    if (blockIdx.x >= total) return;  // nothing to judge, and nobody waits for this workgroup
+    const uint32_t participants = total < gridDim.x ? total : gridDim.x;
     uint32_t judged = 0;
-    for (uint32_t k = blockIdx.x; k < chunk; k += gridDim.x) {
-        const uint32_t pos = cursor + k;
-        if (pos >= rows) break;
-        if (k != blockIdx.x) {  // later rounds: give up once an earlier position has been accepted
+    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+        uint32_t j = 0;
+        while (item >= sStart[j + 1]) ++j;
+        const uint32_t pos = sCursor[j] + (item - sStart[j]);
+        if (item != blockIdx.x) {  // later rounds: skip what lies behind an accepted position
             if (threadIdx.x == 0)
-                shared[2] = __hip_atomic_load(&state->firstHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                shared[2] = __hip_atomic_load(&state->slot[j].firstHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             const uint32_t best = shared[2];
             __syncthreads();
-            if (best < pos) break;
+            if (best < pos) continue;
         }
         if (cluster[pos] != kNoCluster) continue;
         const uint32_t row = order[pos];
-        const float sim =
-            similarityAsReference(rep, sqRep, table + (size_t)row * numBins, rowSquares[row], numBins, shmA, shmB);
+        const float sim = similarityAsReference(reps + (size_t)sSlot[j].rep * numBins, sSlot[j].sq,
+                                                table + (size_t)row * numBins, rowSquares[row], numBins, shmA, shmB);
         ++judged;
-        if (threadIdx.x == 0 && sim > alpha) atomicMin(&state->firstHit, pos);
+        if (threadIdx.x == 0 && sim > alpha) atomicMin(&state->slot[j].firstHit, pos);
     }
     // the last workgroup to arrive closes the pass
     if (threadIdx.x == 0) {
@@ -178,74 +216,135 @@ __global__ void clusterPass(const uint32_t* __restrict__ table, const uint32_t* 
     __syncthreads();
     if (!shared[0]) return;
     __threadfence();
-    const uint32_t hit = __hip_atomic_load(&state->firstHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t nextCursor, nextChunk;
-    bool newRep = false;
-    if (hit != kNoCluster) {
-        const uint32_t* add = table + (size_t)order[hit] * numBins;
-        for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) rep[i] += add[i];
-        if (threadIdx.x == 0) cluster[hit] = id;
-        newRep = true;
-        nextCursor = hit + 1;
-        // judging costs time even when it runs beside the hit (measured: 21 us per pass at ~300
-        // pairs against 11.5 us at ~30), so the next pass looks twice as far as this hit was
-        const uint32_t gap = 2u * (hit - cursor + 1u);
-        nextChunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
-    } else {
-        nextCursor = cursor + chunk;
-        nextChunk = 4u * chunk > maxChunk ? maxChunk : 4u * chunk;
-    }
-    __syncthreads();
-    uint32_t nextSeed = seed, nextId = id, nextDone = 0;
-    if (nextCursor >= rows) {
-        // the cluster is complete: the first row it left behind seeds the next one
-        if (threadIdx.x == 0) shared[1] = kNoCluster;
-        __syncthreads();
-        for (uint32_t base = seed + 1; base < rows; base += blockDim.x) {
-            const uint32_t p = base + threadIdx.x;
-            if (p < rows && cluster[p] == kNoCluster) atomicMin(&shared[1], p);
-            __syncthreads();
-            const uint32_t sofar = shared[1];
-            __syncthreads();  // nobody updates the slot for the next stretch before everyone has read it
-            if (sofar != kNoCluster) break;
-        }
-        const uint32_t found = shared[1];
-        if (found == kNoCluster) {
-            nextDone = 1;
-        } else {
-            nextSeed = found;
-            nextId = id + 1;
-            const uint32_t* first = table + (size_t)order[found] * numBins;
-            for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) rep[i] = first[i];
-            if (threadIdx.x == 0) cluster[found] = nextId;
-            newRep = true;
-            nextCursor = found + 1;
-            nextChunk = 2u * kClusterMinChunk;
-            if (nextCursor >= rows) nextDone = 1;  // the last row forms its own cluster
-        }
-    }
-    // the representative's sum of squares over the bins that count (UIN arithmetic: wraps)
-    uint32_t nextSq = sqRep;
-    if (newRep) {
+
+    // rep = first (assign) or rep += first (merge); returns the new sum of squares over the bins
+    // that count (UIN arithmetic: wraps).  Every thread only touches the bins it owns.
+    auto absorb = [&](uint32_t* __restrict__ rep, const uint32_t* __restrict__ first, bool merge) {
         if (threadIdx.x == 0) shared[1] = 0;
         __syncthreads();
         uint32_t sq = 0;
-        for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x)
-            if (binCounts(i, blockDim.x, liveWarps)) sq += rep[i] * rep[i];
+        for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
+            const uint32_t v = merge ? rep[i] + first[i] : first[i];
+            rep[i] = v;
+            if (binCounts(i, blockDim.x, liveWarps)) sq += v * v;
+        }
         atomicAdd(&shared[1], sq);
         __syncthreads();
-        nextSq = shared[1];
+        const uint32_t sum = shared[1];
+        __syncthreads();
+        return sum;
+    };
+    // smallest unassigned position in [from, to), kNoCluster if there is none
+    auto firstUnassigned = [&](uint32_t from, uint32_t to) {
+        if (threadIdx.x == 0) shared[1] = kNoCluster;
+        __syncthreads();
+        uint32_t found = kNoCluster;
+        for (uint32_t base = from; base < to; base += blockDim.x) {
+            const uint32_t p = base + threadIdx.x;
+            if (p < to && cluster[p] == kNoCluster) atomicMin(&shared[1], p);
+            __syncthreads();
+            found = shared[1];
+            __syncthreads();  // nobody updates the slot for the next stretch before everyone has read it
+            if (found != kNoCluster) break;
+        }
+        return found;
+    };
+
+    // 1. hits, oldest cluster first (sSlot is this workgroup's working copy; all threads run the
+    //    same control flow, thread 0 does the scalar writes)
+    if (threadIdx.x < active)
+        sHit[threadIdx.x] = __hip_atomic_load(&state->slot[threadIdx.x].firstHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (uint32_t j = 0; j < active; ++j) {
+        const uint32_t hit = sHit[j];
+        const uint32_t cursor = sCursor[j], len = sLen[j], chunk = sSlot[j].chunk;
+        uint32_t newCursor = cursor, newChunk = chunk, newSq = sSlot[j].sq;
+        if (hit != kNoCluster) {
+            newSq = absorb(reps + (size_t)sSlot[j].rep * numBins, table + (size_t)order[hit] * numBins, true);
+            if (threadIdx.x == 0) cluster[hit] = sSlot[j].id;
+            newCursor = hit + 1;
+            // judging costs time even beside the hit, so the next pass looks twice as far as this hit was
+            const uint32_t gap = 2u * (hit - cursor + 1u);
+            newChunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
+        } else if (len) {
+            newCursor = cursor + len;
+            if (len == chunk) newChunk = 4u * chunk > maxChunk ? maxChunk : 4u * chunk;  // not held back by the older cluster
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            sSlot[j].cursor = newCursor;
+            sSlot[j].chunk = newChunk;
+            sSlot[j].sq = newSq;
+            sSlot[j].firstHit = kNoCluster;
+        }
+        __syncthreads();
     }
+    // 2. retire finished clusters (only the oldest can be finished: the others trail it)
+    uint32_t retired = 0, floor = state->floor, freeReps = state->freeReps, nextId = state->nextId;
+    while (retired < active && sSlot[retired].cursor >= rows) {
+        freeReps |= 1u << sSlot[retired].rep;
+        if (sSlot[retired].seed + 1 > floor) floor = sSlot[retired].seed + 1;
+        ++retired;
+    }
+    uint32_t left = active - retired;
+    __syncthreads();
+    if (retired) {
+        if (threadIdx.x == 0)
+            for (uint32_t j = 0; j < left; ++j) sSlot[j] = sSlot[j + retired];
+        __syncthreads();
+    }
+    // 3. the successor of the youngest cluster starts at the first row that cluster passed over;
+    //    with nothing in flight, at the first row that has no cluster at all
+    uint32_t done = 0;
+    if (left < maxActive) {
+        uint32_t from, to;
+        if (left) {
+            from = sSlot[left - 1].scan;
+            to = sSlot[left - 1].cursor < rows ? sSlot[left - 1].cursor : rows;
+        } else {
+            from = floor;
+            to = rows;
+        }
+        const uint32_t found = firstUnassigned(from, to);
+        if (found == kNoCluster) {
+            if (left == 0) done = 1;
+            else if (threadIdx.x == 0 && to > from) sSlot[left - 1].scan = to;  // all of that stretch is assigned
+        } else {
+            uint32_t r = 0;
+            while (!((freeReps >> r) & 1u)) ++r;
+            freeReps &= ~(1u << r);
+            ++nextId;
+            const uint32_t sq = absorb(reps + (size_t)r * numBins, table + (size_t)order[found] * numBins, false);
+            if (threadIdx.x == 0) {
+                cluster[found] = nextId;
+                if (left) sSlot[left - 1].scan = found + 1;
+                ClusterSlot c;
+                c.seed = found;
+                c.cursor = found + 1;
+                c.chunk = 2u * kClusterMinChunk;
+                c.id = nextId;
+                c.sq = sq;
+                c.firstHit = kNoCluster;
+                c.scan = found + 1;
+                c.rep = r;
+                sSlot[left] = c;
+            }
+            // seeded by the very last position with nothing else in flight: that cluster is complete
+            if (left == 0 && found + 1 >= rows) done = 1;
+            ++left;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x < left) state->slot[threadIdx.x] = sSlot[threadIdx.x];
     if (threadIdx.x == 0) {
-        state->seed = nextSeed;
-        state->clusterId = nextId;
-        state->cursor = nextCursor;
-        state->chunk = nextChunk;
-        state->sqRep = nextSq;
-        state->firstHit = kNoCluster;
+        state->numActive = left;
+        state->nextId = nextId;
+        state->floor = floor;
+        state->freeReps = freeReps;
         state->arrived = 0;
         state->passes += 1;
-        state->done = nextDone;
+        state->done = done;
     }
 }
 
@@ -260,7 +359,7 @@ __global__ void clusterInitSquares(const uint32_t* __restrict__ rep, uint32_t nu
         if (binCounts(i, blockDim.x, liveWarps)) sq += rep[i] * rep[i];
     atomicAdd(&total, sq);
     __syncthreads();
-    if (threadIdx.x == 0) state->sqRep = total;
+    if (threadIdx.x == 0) state->slot[0].sq = total;
 }
 
 }  // namespace bsmr
