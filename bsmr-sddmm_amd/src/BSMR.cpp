@@ -12,6 +12,9 @@
 #include <cstdlib>
 #include <string>
 
+#include <omp.h>
+#include "util.hpp"
+
 #include "BSMR.hpp"
 
 #include <algorithm>
@@ -157,7 +160,7 @@ RPHM::RPHM(const sparseMatrix::CSR<float>& matrix, const BSMR& bsmr, int device)
     sparseRelativeRows_.resize(numSparse);
     sparseColIndices_.resize(numSparse);
 
-#pragma omp parallel
+#pragma omp parallel num_threads(util::hostThreads(omp_get_max_threads()))
     {
         std::vector<PanelEntry> entries;
 #pragma omp for schedule(dynamic, 8)
@@ -347,7 +350,7 @@ bool check_rowReordering(const sparseMatrix::CSR<float>& m, const RPHM& rphm) {
 bool check_colReordering(const sparseMatrix::CSR<float>& m, const BSMR& bsmr, const float delta) {
     const UIN threshold = static_cast<UIN>(std::ceil(delta * BLOCK_SIZE));
     bool ok = true;
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(util::hostThreads(omp_get_max_threads()))
     for (long long p = 0; p < bsmr.numRowPanels(); ++p) {
         if (!ok) continue;
         std::vector<PanelEntry> entries;
@@ -466,7 +469,7 @@ std::pair<UIN, float> calculateNumDenseBlocksAndAverageDensityInOriginalMatrix(
     const UIN numPanels = ceilDiv(matrix.row(), ROW_PANEL_SIZE);
     // per panel: (column block id, nnz) for the non-empty blocks, ascending
     std::vector<std::vector<std::pair<UIN, UIN>>> census(numPanels);
-#pragma omp parallel
+#pragma omp parallel num_threads(util::hostThreads(omp_get_max_threads()))
     {
         std::vector<UIN> ids;
 #pragma omp for schedule(dynamic, 64)
@@ -506,7 +509,7 @@ void evaluationReordering(const sparseMatrix::CSR<float>& matrix, const BSMR& bs
     const int numPanels = bsmr.numRowPanels();
     std::vector<std::vector<UIN>> nnzPerDenseBlock(numPanels);
     std::vector<UIN> residue(numPanels, 0);
-#pragma omp parallel
+#pragma omp parallel num_threads(util::hostThreads(omp_get_max_threads()))
     {
         std::vector<PanelEntry> entries;
 #pragma omp for schedule(dynamic, 16)

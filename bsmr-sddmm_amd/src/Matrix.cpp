@@ -7,6 +7,8 @@
 // parsing, sort-based duplicate detection (the reference inserts every entry
 // into a std::set), size_t offsets.
 
+#include <omp.h>
+
 #include "Matrix.hpp"
 
 #include <algorithm>
@@ -245,7 +247,7 @@ bool hasDuplicateInRows(const std::vector<UIN>& rowOffsets, const std::vector<UI
                         UIN* badRow = nullptr, UIN* badCol = nullptr) {
     const long long rows = static_cast<long long>(rowOffsets.size()) - 1;
     bool dup = false;
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for schedule(dynamic, 256) num_threads(util::hostThreads(omp_get_max_threads()))
     for (long long r = 0; r < rows; ++r) {
         if (dup) continue;
         const UIN b = rowOffsets[r], e = rowOffsets[r + 1];

@@ -16,6 +16,9 @@
 #include <numeric>
 #include <vector>
 
+#include <omp.h>
+#include "util.hpp"
+
 #include "BSMR.hpp"
 
 std::pair<UIN, UIN> analysisDescendingOrderColSegment(
@@ -45,7 +48,7 @@ void colReordering_cpu(const sparseMatrix::CSR<float>& matrix, const UIN numRowP
     std::vector<UIN> numDense(numRowPanels, 0), numSparse(numRowPanels, 0),
         sparseEntries(numRowPanels, 0);
 
-#pragma omp parallel
+#pragma omp parallel num_threads(util::hostThreads(omp_get_max_threads()))
     {
         std::vector<UIN> ids;     // column id of every entry of the panel
         std::vector<UIN> cols;    // distinct columns, ascending
@@ -104,7 +107,7 @@ void colReordering_cpu(const sparseMatrix::CSR<float>& matrix, const UIN numRowP
 
     denseCols.resize(denseColOffsets[numRowPanels]);
     sparseCols.resize(sparseColOffsets[numRowPanels]);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(util::hostThreads(omp_get_max_threads()))
     for (long long p = 0; p < static_cast<long long>(numRowPanels); ++p) {
         const std::vector<UIN>& c = panelCols[p];
         std::copy(c.begin(), c.begin() + numDense[p], denseCols.begin() + denseColOffsets[p]);

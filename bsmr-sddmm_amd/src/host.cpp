@@ -1,6 +1,9 @@
 // CPU products (reference src/host.cpp:5-124).  Strictly sequential k loop per
 // output so the rounding sequence is the reference's; rows are distributed
 // over OpenMP threads.
+#include <omp.h>
+#include "util.hpp"
+
 #include "host.hpp"
 
 #include <iostream>
@@ -30,7 +33,7 @@ void dmm_cpu(const Matrix<T>& A, const Matrix<T>& B, Matrix<T>& C) {
     if (!shapesAgree<T>(A.row(), A.col(), B.row(), B.col(), C.row(), C.col())) return;
     const UIN K = A.col();
     const long long total = static_cast<long long>(C.row()) * C.col();
-#pragma omp parallel for
+#pragma omp parallel for num_threads(util::hostThreads(omp_get_max_threads()))
     for (long long i = 0; i < total; ++i)
         C[static_cast<size_t>(i)] = dotK(A, B, C.rowOfValueIndex(static_cast<UIN>(i)),
                                          C.colOfValueIndex(static_cast<UIN>(i)), K);
@@ -42,7 +45,7 @@ void sddmm_cpu(const Matrix<T>& A, const Matrix<T>& B, const sparseMatrix::CSR<T
     if (!shapesAgree<T>(A.row(), A.col(), B.row(), B.col(), P.row(), P.col())) return;
     const UIN K = A.col();
     std::vector<T>& out = P.setValues();
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for schedule(dynamic, 64) num_threads(util::hostThreads(omp_get_max_threads()))
     for (long long row = 0; row < static_cast<long long>(S.row()); ++row)
         for (UIN e = S.rowOffsets()[row]; e < S.rowOffsets()[row + 1]; ++e)
             out[e] = dotK(A, B, static_cast<UIN>(row), S.colIndices()[e], K);
@@ -54,7 +57,7 @@ void sddmm_cpu(const Matrix<T>& A, const Matrix<T>& B, const sparseMatrix::COO<T
     if (!shapesAgree<T>(A.row(), A.col(), B.row(), B.col(), P.row(), P.col())) return;
     const UIN K = A.col();
     std::vector<T>& out = P.setValues();
-#pragma omp parallel for
+#pragma omp parallel for num_threads(util::hostThreads(omp_get_max_threads()))
     for (long long e = 0; e < static_cast<long long>(S.nnz()); ++e)
         out[e] = dotK(A, B, S.rowIndices()[e], S.colIndices()[e], K);
 }

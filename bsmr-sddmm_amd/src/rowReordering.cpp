@@ -41,6 +41,7 @@
 #include <vector>
 
 #include <omp.h>
+#include "util.hpp"
 
 #include "BSMR.hpp"
 #include "bsmr_hip.h"
@@ -124,7 +125,7 @@ RowEncodings buildEncodings(const sparseMatrix::CSR<float>& m, const UIN binWidt
     enc.squares.assign(rows, 0);
     std::vector<UIN> numBins(rows, 0);
     // pass 1: number of touched bins per row
-#pragma omp parallel
+#pragma omp parallel num_threads(util::hostThreads(omp_get_max_threads()))
     {
         std::vector<UIN> bins;
 #pragma omp for schedule(dynamic, 512)
@@ -140,7 +141,7 @@ RowEncodings buildEncodings(const sparseMatrix::CSR<float>& m, const UIN binWidt
     for (size_t r = 0; r < rows; ++r) enc.offsets[r + 1] = enc.offsets[r] + numBins[r];
     enc.items.resize(enc.offsets[rows]);
     // pass 2: fill (bin, count) and the dispersion score
-#pragma omp parallel
+#pragma omp parallel num_threads(util::hostThreads(omp_get_max_threads()))
     {
         std::vector<UIN> bins;
 #pragma omp for schedule(dynamic, 512)
@@ -358,7 +359,7 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
     Representative rep(blockSum, numBins);
     // one short parallel region per chunk: beyond ~16 threads the barriers cost more than the
     // similarities (measured: a 128-thread box ran this 2-3x slower than an 8-thread one)
-    const int maxThreads = std::min(omp_get_max_threads(), 16);
+    const int maxThreads = std::min(util::hostThreads(omp_get_max_threads()), 16);
     std::vector<PairScratch> scratch;
     scratch.reserve(maxThreads);
     for (int t = 0; t < maxThreads; ++t) scratch.emplace_back(numBins, blockSum.nodes());

@@ -4,11 +4,15 @@ import subprocess
 import sys
 from pathlib import Path
 
-import numpy as np
-import pytest
-
 REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO / "bsmr-sddmm_amd" / "python"))
+import hostinfo  # noqa: E402
+
+hostinfo.limit_openmp_threads()   # before any OpenMP runtime starts: honour the container's CPU quota
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
+
 sys.path.insert(0, str(REPO / "oracle"))
 sys.path.insert(0, str(REPO))
 
