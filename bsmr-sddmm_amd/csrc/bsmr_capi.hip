@@ -41,6 +41,7 @@ struct DenseFormat {
     DenseItem* items = nullptr;
     uint32_t numItems = 0;
     uint32_t maxItemBlocks = 0;
+    uint32_t streamWaves = 4;      // waves per workgroup of the streaming kernel (1: items of <= 8 blocks)
     bool stageInLds = false;       // assemble the row windows in LDS and write them out coalesced
     uint64_t numBlocks = 0, numTiles = 0, unionColumns = 0;
 };
@@ -204,18 +205,20 @@ int launchGroupsT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
 }
 
 // streaming form for ungrouped plans whose items hold <= 32 blocks (8 per wave)
-template <int KS, int MODE, typename TileT>
+template <int KS, int MODE, typename TileT, int WAVES = bsmr::kWavesPerWG>
 int launchStreamT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, const TileT* tiles, float* P,
                   hipStream_t s) {
-    auto kernel = bsmr::denseStream<KS, MODE, TileT>;
-    const size_t lds = (size_t)bsmr::kWavesPerWG * bsmr::streamSlots(KS) * 1024u * KS;  // wave-private ring
+    if (WAVES == bsmr::kWavesPerWG && f.streamWaves == 1)
+        return launchStreamT<KS, MODE, TileT, 1>(f, A16, B16, tiles, P, s);
+    auto kernel = bsmr::denseStream<KS, MODE, TileT, 8, WAVES>;
+    const size_t lds = (size_t)WAVES * bsmr::streamSlots(KS) * 1024u * KS;  // wave-private ring
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         BSMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         raised = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(f.numItems), dim3(bsmr::kThreads), lds, s, A16, B16, f.groupRows, f.rowBase,
+    hipLaunchKernelGGL(kernel, dim3(f.numItems), dim3(WAVES * bsmr::kWave), lds, s, A16, B16, f.groupRows, f.rowBase,
                        f.blockCols, tiles, f.items, P);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
@@ -580,7 +583,24 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         bsmr::PackOptions opt;
         const int forcedGroup = envInt("BSMR_DENSE_GROUP", 0);
         opt.group = forcedGroup == 1 || forcedGroup == 2 || forcedGroup == 4 ? forcedGroup : 1;
-        opt.blocksPerItem = envInt("BSMR_DENSE_BLOCKS_PER_WG", 32);
+        // Ungrouped plans run the streaming kernel with one wave per workgroup (BSMR_STREAM_WAVES=4:
+        // four).  Blocks per wave, measured on MI355X (nips-like 230 blocks per panel: 8 best;
+        // mycielskian14/15 with 10-15: 3-4 best, dense kernel 11.2 -> 7.2 us and 23.3 -> 17.2 us;
+        // nips-like delta=0.3, 2003 blocks in all: 2): enough waves to fill the chip, at least four
+        // items per panel so that an item stays inside one XCD's column slice, never more than 8.
+        const int streamWaves = envInt("BSMR_STREAM_WAVES", 1) == 4 ? 4 : 1;
+        int autoBlocks = 32;
+        if (streamWaves == 1 && forcedGroup <= 1) {
+            const uint64_t numBlocks = d->block_offsets[P];
+            uint64_t densePanels = 0;
+            for (uint32_t q = 0; q < P; ++q) densePanels += d->block_offsets[q + 1] > d->block_offsets[q];
+            const uint64_t perPanel = densePanels ? numBlocks / densePanels : 0;
+            uint64_t b = std::min<uint64_t>(numBlocks / 2560, perPanel / 4);
+            b = std::max<uint64_t>(3, std::min<uint64_t>(8, b));
+            if (numBlocks / b < 1500) b = 2;
+            autoBlocks = (int)b;
+        }
+        opt.blocksPerItem = envInt("BSMR_DENSE_BLOCKS_PER_WG", autoBlocks);
         opt.sparsePerItem = envInt("BSMR_SPARSE_ENTRIES_PER_WG", 256);
         opt.forceWideTiles = envInt("BSMR_FORCE_TILE32", 0) != 0;
         opt.columnOrder = envInt("BSMR_COLUMN_ORDER", 1) != 0;
@@ -614,6 +634,7 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
 
         st = uploadDense(p->fmt[0], pk, p->indexBytes);
         p->fmt[0].stageInLds = outputMode == 2;
+        p->fmt[0].streamWaves = streamWaves == 1 && p->fmt[0].maxItemBlocks <= 8 ? 1 : 4;
         if (st == BSMR_OK) st = upload(p->panelRows, pk.panelRows, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->entryCol, pk.entryCol, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->entryDst, pk.entryDst, p->indexBytes);
@@ -624,6 +645,7 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         if (st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8) {
             bsmr::PackedPlan pk4;
             opt.group = 4;
+            opt.blocksPerItem = envInt("BSMR_DENSE_BLOCKS_PER_WG", 32);
             st = bsmr::packPlan(d, opt, pk4);
             if (st == BSMR_OK && pk4.unionColumns * 4 <= pk.unionColumns * 3)
                 st = uploadDense(p->fmt[1], pk4, p->indexBytes);

@@ -389,8 +389,8 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
 // throughput, not by the latency of one gather, so the smaller footprint is kept.
 constexpr uint32_t streamSlots(int /*KS*/) { return 2u; }
 
-template <int KS, int MODE, typename TileT, int MAXB = 8>
-__global__ void __launch_bounds__(kThreads)
+template <int KS, int MODE, typename TileT, int MAXB = 8, int WAVES = kWavesPerWG>
+__global__ void __launch_bounds__(WAVES * kWave)
 denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
             const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ rowBaseTable,
             const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
@@ -412,8 +412,9 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t r = lane & 15u, g = lane >> 4;
     uint8_t* myLds = lds + wave * (SLOTS * blkBytes);
-    // blocks of this wave: item.first + wave + 4m, m < myCount
-    const uint32_t myCount = item.count > wave ? min((item.count - wave + 3u) >> 2, (uint32_t)MAXB) : 0u;
+    // blocks of this wave: item.first + wave + WAVES * m, m < myCount
+    const uint32_t myCount =
+        item.count > wave ? min((item.count - wave + (uint32_t)WAVES - 1u) / (uint32_t)WAVES, (uint32_t)MAXB) : 0u;
     if (myCount == 0) return;
     const uint32_t myFirst = item.first + wave;
 
@@ -421,11 +422,11 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     uint32_t cols[CREG];   // lane l, register q: column (l & 15) of my block 4q + (l >> 4)
 #pragma unroll
     for (uint32_t q = 0; q < CREG; ++q)
-        cols[q] = blockCols[(size_t)(myFirst + 4u * min(4u * q + g, myCount - 1u)) * 16u + r];
+        cols[q] = blockCols[(size_t)(myFirst + (uint32_t)WAVES * min(4u * q + g, myCount - 1u)) * 16u + r];
     TileRaw tile[MAXB];
 #pragma unroll
     for (uint32_t m = 0; m < (uint32_t)MAXB; ++m)
-        if (m < myCount) tile[m] = loadTile<TileT>(tiles, (size_t)(myFirst + 4u * m), lane);
+        if (m < myCount) tile[m] = loadTile<TileT>(tiles, (size_t)(myFirst + (uint32_t)WAVES * m), lane);
     const uint32_t rowSlot = item.group * 16u;
     uint32_t rowBase[4];
 #pragma unroll

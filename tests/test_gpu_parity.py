@@ -137,6 +137,8 @@ def test_large_k_sparse_without_lds(engine, oracle):
     {"BSMR_OUTPUT_MODE": "2"}, {"BSMR_OUTPUT_MODE": "2", "BSMR_DENSE_GROUP": "4"},
     {"BSMR_OUTPUT_MODE": "2", "BSMR_DENSE_GROUP": "2", "BSMR_DENSE_BLOCKS_PER_WG": "7"},
     {"BSMR_DENSE_BLOCKS_PER_WG": "1"}, {"BSMR_DENSE_BLOCKS_PER_WG": "5", "BSMR_DENSE_GROUP": "2"},
+    {"BSMR_STREAM_WAVES": "4"}, {"BSMR_STREAM_WAVES": "4", "BSMR_DENSE_BLOCKS_PER_WG": "13"},
+    {"BSMR_DENSE_BLOCKS_PER_WG": "8"}, {"BSMR_DENSE_BLOCKS_PER_WG": "32"},
 ])
 @pytest.mark.parametrize("K", [32, 128, 512])
 def test_plan_knobs(engine, oracle, monkeypatch, knobs, K):
