@@ -418,38 +418,18 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     if (myCount == 0) return;
     const uint32_t myFirst = item.first + wave;
 
-    // ---- prologue: every ordinary load of the wave ----
+    // ---- prologue, two dependent round trips after the item record ----
+    // 1. what the gathers and the A fragments are addressed with
     uint32_t cols[CREG];   // lane l, register q: column (l & 15) of my block 4q + (l >> 4)
 #pragma unroll
     for (uint32_t q = 0; q < CREG; ++q)
         cols[q] = blockCols[(size_t)(myFirst + (uint32_t)WAVES * min(4u * q + g, myCount - 1u)) * 16u + r];
-    TileRaw tile[MAXB];
-#pragma unroll
-    for (uint32_t m = 0; m < (uint32_t)MAXB; ++m)
-        if (m < myCount) tile[m] = loadTile<TileT>(tiles, (size_t)(myFirst + (uint32_t)WAVES * m), lane);
     const uint32_t rowSlot = item.group * 16u;
-    uint32_t rowBase[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        rowBase[i] = WINDOWED ? rowBaseTable[(size_t)itemId * 16u + 4u * g + i] : rowBaseTable[rowSlot + 4u * g + i];
-    u32x4 a[KS];
-    {
-        const uint16_t* aRow = A16 + (size_t)groupRows[rowSlot + r] * K + g * 8u;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const u32x4*>(aRow + s * 32);
-    }
-    // Drain them now and mark them consumed: while an LDS-DMA is in flight the compiler
-    // would otherwise put a full vmcnt(0) in front of the first use of any of these.
+    uint32_t myRow = groupRows[rowSlot + r];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[s]));
-#pragma unroll
     for (uint32_t q = 0; q < CREG; ++q) asm volatile("" : "+v"(cols[q]));
-#pragma unroll
-    for (uint32_t m = 0; m < (uint32_t)MAXB; ++m) asm volatile("" : "+v"(tile[m]));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(rowBase[i]));
-
+    asm volatile("" : "+v"(myRow));
     // ring of SLOTS block images per wave: SLOTS-1 gathers stay in flight (a gather takes
     // ~1200 cycles under load, a block's MFMAs ~400: measured with in-kernel stamps)
     auto gather = [&](uint32_t m) {  // my block m -> slot m % SLOTS
@@ -475,9 +455,29 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
         else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     };
 
+    // 2. first gather, then the A fragments, destinations and row bases, then the second gather: all
+    //    in flight together.  The A loads are issued through inline assembly so that the compiler,
+    //    which cannot count past an LDS-DMA, does not put a vmcnt(0) in front of their first use;
+    //    the counted wait of the first block (all but the youngest KS operations) covers them.
     f32x4 acc[MAXB];
+    gather(0);
+    u32x4 a[KS];
+    {
+        const uint16_t* aRow = A16 + (size_t)myRow * K + g * 8u;
 #pragma unroll
-    for (uint32_t m = 0; m + 1 < SLOTS; ++m)
+        for (int s = 0; s < KS; ++s)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[s]) : "v"(aRow + s * 32) : "memory");
+    }
+    TileRaw tile[MAXB];
+#pragma unroll
+    for (uint32_t m = 0; m < (uint32_t)MAXB; ++m)
+        if (m < myCount) tile[m] = loadTile<TileT>(tiles, (size_t)(myFirst + (uint32_t)WAVES * m), lane);
+    uint32_t rowBase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        rowBase[i] = WINDOWED ? rowBaseTable[(size_t)itemId * 16u + 4u * g + i] : rowBaseTable[rowSlot + 4u * g + i];
+#pragma unroll
+    for (uint32_t m = 1; m + 1 < SLOTS; ++m)
         if (m < myCount) gather(m);
 #pragma unroll
     for (uint32_t m = 0; m < (uint32_t)MAXB; ++m) {
@@ -488,6 +488,10 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
         if (younger == 0) waitInFlight(0);
         else if (younger == 1) waitInFlight(1);
         else waitInFlight(2);
+        if (m == 0) {  // the A fragments have landed with the first block
+#pragma unroll
+            for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[s]));
+        }
         const uint8_t* bCol = myLds + (m % SLOTS) * blkBytes + r * rowBytes;
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
