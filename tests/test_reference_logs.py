@@ -141,3 +141,40 @@ def test_oracle_clustering_reproduces_reference_logs(engine, oracle, name, alpha
         assert clusters == runs_of(name, alpha)[0]["bsmr_numClusters"]
         pipe = engine.Pipeline(csr, alpha=alpha, delta=0.3, block_size=BIN_WIDTH, device=-1)
         assert np.array_equal(pipe.array("reorderedRows"), perm)
+
+
+def test_cli_sweep_writes_the_reference_logs(engine, tmp_path):
+    """`BSMR-sddmm -f Trefethen_20000.mtx -t 1 -l dir/` (sddmm_testMode, src/sddmm.cu:62-118) without a
+    GPU: the 140 log files carry the reference's names (BSMR_k_<K>_a_<alpha>_d_<delta>.log) and, in
+    the reference's `[key : value]` format, the same pipeline values the reference logged."""
+    import re
+    import subprocess
+    rows, cols, ro, ci = synth.trefethen_pattern(20000)
+    mtx = tmp_path / "Trefethen_20000.mtx"
+    synth.write_mtx_columnwise(mtx, rows, cols, ro, ci)
+    logs = tmp_path / "logs"
+    logs.mkdir()
+    exe = Path(__file__).resolve().parent.parent / "bsmr-sddmm_amd" / "bin" / "BSMR-sddmm"
+    env = dict(__import__("os").environ, BSMR_CLUSTER="host")
+    subprocess.run([str(exe), "-f", str(mtx), "-t", "1", "-l", str(logs) + "/"], capture_output=True, text=True,
+                   timeout=600, env=env)
+    names = sorted(p.name for p in logs.iterdir())
+    assert len(names) == 140
+    keys = ("NumRowPanel", "original_numDenseBlock", "original_averageDensity", "bsmr_numClusters",
+            "bsmr_numDenseBlock", "bsmr_averageDensity", "bsmr_numDenseThreadBlocks", "bsmr_numSparseThreadBlocks",
+            "bsmr_threadBlockRatio", "bsmr_numDenseData", "bsmr_numSparseData", "bsmr_dataRatio")
+    checked = 0
+    for run in GOLDEN["Trefethen_20000"]["runs"]:
+        for k in (32, 64, 128, 256):
+            a, d = (f"{v:g}" for v in (run["alpha"], run["delta"]))
+            path = logs / f"BSMR_k_{k}_a_{a}_d_{d}.log"
+            assert path.name in names, path.name
+            text = path.read_text()
+            assert text.count("---New data---") == 1
+            got = {key.strip(): val.strip() for key, val in re.findall(r"\[([^\[\]:]+?)\s*:\s*([^\[\]]*)\]", text)}
+            assert (got["K"], got["M"], got["N"], got["NNZ"]) == (str(k), "20000", "20000", "287233")
+            assert (got["bsmr_alpha"], got["bsmr_delta"]) == (f"{run['alpha']:.2f}", f"{run['delta']:.2f}")
+            for key in keys:
+                assert got[key] == str(run[key]), (path.name, key, got[key], run[key])
+            checked += 1
+    assert checked == 140
