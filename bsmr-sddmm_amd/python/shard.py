@@ -142,4 +142,7 @@ def run_sharded(eng, torch, dist, dev, rank, world, make_pattern, K, alpha, delt
                    "parallelism": f"row-range shards x{world}, B replicated, one RCCL gather-v to rank 0 per step"},
         "compute_only_ms_max": round(float(ct.item()), 5),
         "plan_build_s": round(plan_s, 3),
+        # this rank's shard, for the caller's roofline (used on rank 0)
+        "rank0": {"kernels_ms": kt, "pattern": (lrows, cols, lro, lci), "dense_tiles": pipe.dense_choice(K)["tiles"],
+                  "sparse_lowp": bool(pipe.plan_stats()["sparse_lowp"])},
     }
