@@ -88,6 +88,8 @@ namespace {
 constexpr uint64_t kGroupedGatherBytes = 200ull << 20;
 
 thread_local std::string g_lastHipError;
+// batch of the call being launched on this thread (bsmr_sddmm_batch sets it for the duration of the call)
+thread_local bsmr::Batch g_batch{0, 0, 0, 1};
 
 inline bool hipOk(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
@@ -198,8 +200,8 @@ int launchGroupsT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         raised = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(f.numItems), dim3(bsmr::kThreads), lds, s, A16, B16, f.groupRows, f.rowBase,
-                       f.winLen, f.winMask, f.blockCols, tiles, f.blockMask, f.items, P);
+    hipLaunchKernelGGL(kernel, dim3(f.numItems, g_batch.count), dim3(bsmr::kThreads), lds, s, A16, B16, f.groupRows, f.rowBase,
+                       f.winLen, f.winMask, f.blockCols, tiles, f.blockMask, f.items, P, g_batch);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -218,8 +220,8 @@ int launchStreamT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         raised = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(f.numItems), dim3(WAVES * bsmr::kWave), lds, s, A16, B16, f.groupRows, f.rowBase,
-                       f.blockCols, tiles, f.items, P);
+    hipLaunchKernelGGL(kernel, dim3(f.numItems, g_batch.count), dim3(WAVES * bsmr::kWave), lds, s, A16, B16, f.groupRows, f.rowBase,
+                       f.blockCols, tiles, f.items, P, g_batch);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -275,17 +277,17 @@ int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uin
     }
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
     if (f.tiles8)
-        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint8_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A16,
+        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint8_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A16,
                            B16, K, f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items,
-                           f.numItems, P);
+                           f.numItems, P, g_batch);
     else if (f.tiles16)
-        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint16_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A16,
+        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint16_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A16,
                            B16, K, f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items,
-                           f.numItems, P);
+                           f.numItems, P, g_batch);
     else
-        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint32_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A16,
+        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint32_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A16,
                            B16, K, f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items,
-                           f.numItems, P);
+                           f.numItems, P, g_batch);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -297,14 +299,14 @@ int launchDenseCvt(const bsmr_plan* p, uint32_t K, const float* A, const float* 
     if (f.numItems == 0) return BSMR_OK;
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
     if (f.tiles8)
-        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint8_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items, f.numItems, P);
+        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint8_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items, f.numItems, P, g_batch);
     else if (f.tiles16)
-        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint16_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items, f.numItems, P);
+        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint16_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items, f.numItems, P, g_batch);
     else
-        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint32_t>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items, f.numItems, P);
+        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint32_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items, f.numItems, P, g_batch);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -315,14 +317,14 @@ int launchDense32(const bsmr_plan* p, uint32_t K, const float* A, const float* B
     if (f.numItems == 0) return BSMR_OK;
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
     if (f.tiles8)
-        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint8_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
-                           f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items, f.numItems, P);
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint8_t>, dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
+                           f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items, f.numItems, P, g_batch);
     else if (f.tiles16)
-        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint16_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
-                           f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items, f.numItems, P);
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint16_t>, dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
+                           f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items, f.numItems, P, g_batch);
     else
-        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint32_t>, dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
-                           f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items, f.numItems, P);
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint32_t>, dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
+                           f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items, f.numItems, P, g_batch);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -351,11 +353,11 @@ int launchSparseT(const bsmr_plan* p, uint32_t K, const float* A, const float* B
     const size_t lds = (size_t)16 * (K + bsmr::kSparseLdsPad) * sizeof(float);
     const uint32_t wgs = p->numSparseItems;  // no padding: every workgroup reads its item
     if (lds <= 64 * 1024) {
-        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, true, CPL>), dim3(wgs), dim3(bsmr::kThreads), lds, s, A, B,
-                           K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P);
+        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, true, CPL>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), lds, s, A, B,
+                           K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, g_batch);
     } else {
-        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, false, CPL>), dim3(wgs), dim3(bsmr::kThreads), 0, s, A, B,
-                           K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P);
+        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, false, CPL>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B,
+                           K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, g_batch);
     }
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
@@ -382,11 +384,11 @@ int launchSparse16T(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const u
     const size_t lds = (size_t)16 * (2u * K + bsmr::kSparseLdsPad16);
     const uint32_t wgs = p->numSparseItems;
     if (lds <= 64 * 1024) {
-        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, true, CPL>), dim3(wgs), dim3(bsmr::kThreads), lds, s,
-                           A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P);
+        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, true, CPL>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), lds, s,
+                           A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, g_batch);
     } else {
-        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, false, CPL>), dim3(wgs), dim3(bsmr::kThreads), 0, s,
-                           A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P);
+        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, false, CPL>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s,
+                           A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, g_batch);
     }
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
@@ -729,6 +731,40 @@ int bsmr_sddmm(bsmr_plan* plan, uint32_t K, const float* A, const float* B, floa
     BSMR_HIP(hipSetDevice(plan->device));
     if (needsWorkspace(plan, mode) && (st = reserve(plan, K)) != BSMR_OK) return st;
     return runPieces(plan, K, A, B, P, mode, static_cast<hipStream_t>(stream), 7);
+}
+
+int bsmr_sddmm_batch(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, uint32_t num_batches,
+                     int mode, void* stream) {
+    int st = checkCall(plan, K, A, B, P, mode);
+    if (st != BSMR_OK) return st;
+    if (num_batches == 0) return BSMR_OK;
+    if (num_batches > 65535u || (uint64_t)K * num_batches > 0xFFFFFFFFull) return BSMR_ERR_INVALID_ARG;
+    BSMR_HIP(hipSetDevice(plan->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool lowp = needsWorkspace(plan, mode);
+    if (lowp) {
+        // the batches are contiguous, so one conversion pass covers all of them
+        if ((st = reserve(plan, K * num_batches)) != BSMR_OK) return st;
+        st = mode == BSMR_COMPUTE_F16 ? launchConvert<0>(plan, K * num_batches, A, B, plan->A16, plan->B16, s)
+                                      : launchConvert<1>(plan, K * num_batches, A, B, plan->A16, plan->B16, s);
+        if (st != BSMR_OK) return st;
+    }
+    struct Restore {
+        ~Restore() { g_batch = bsmr::Batch{0, 0, 0, 1}; }
+    } restore;
+    g_batch = bsmr::Batch{(uint64_t)plan->M * K, (uint64_t)plan->N * K, plan->nnz, num_batches};
+    return runPieces(plan, K, A, B, P, mode, s, 6);  // dense + residue, grid y = batch
+}
+
+int bsmr_batched_transpose(uint32_t width, uint32_t height, uint32_t num_batches, const float* in_dev, float* out_dev,
+                           void* stream) {
+    if (!in_dev || !out_dev) return BSMR_ERR_INVALID_ARG;
+    if (width == 0 || height == 0 || num_batches == 0) return BSMR_OK;
+    if (num_batches > 65535u || (height + 31) / 32 > 65535u) return BSMR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bsmr::batchedTranspose, dim3((width + 31) / 32, (height + 31) / 32, num_batches),
+                       dim3(bsmr::kThreads), 0, static_cast<hipStream_t>(stream), in_dev, out_dev, width, height);
+    BSMR_HIP(hipGetLastError());
+    return BSMR_OK;
 }
 
 int bsmr_convert_operands(bsmr_plan* plan, uint32_t K, const float* A, const float* B, void* A16,

@@ -51,6 +51,13 @@ constexpr int kWavesPerWG = kThreads / kWave;
 constexpr int kMaxGroup = 4;            // row panels per group (H)
 
 // One unit of dense work: blocks [first, first+count) (global block ids) of row group `group`.
+// Strided batch (sddmm_gpu_batch of the reference, src/sddmmKernel.cu:2764-2869): problem b reads
+// A + b * strideA, B + b * strideB and writes P + b * strideP (element strides); b = blockIdx.y.
+struct Batch {
+    uint64_t strideA, strideB, strideP;
+    uint32_t count;
+};
+
 struct DenseItem {
     uint32_t group;
     uint32_t first;
@@ -180,7 +187,10 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
             const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ rowBaseTable,
             const uint16_t* __restrict__ winLen, const uint32_t* __restrict__ winMask,
             const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
-            const uint8_t* __restrict__ blockMask, const DenseItem* __restrict__ items, float* __restrict__ P) {
+            const uint8_t* __restrict__ blockMask, const DenseItem* __restrict__ items, float* __restrict__ P, Batch batch) {
+    A16 += blockIdx.y * batch.strideA;  // batched call: problem blockIdx.y of a strided batch
+    B16 += blockIdx.y * batch.strideB;
+    P += blockIdx.y * batch.strideP;
     // 8-bit tiles: offsets into a per-(item, row) window of P; rowBaseTable (window
     //   base), winLen and winMask are indexed by item.  With LDS_STAGE the windows are
     //   assembled in LDS and written out coalesced at the end (ownership bitmap =
@@ -394,7 +404,10 @@ __global__ void __launch_bounds__(WAVES * kWave)
 denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
             const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ rowBaseTable,
             const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
-            const DenseItem* __restrict__ items, float* __restrict__ P) {
+            const DenseItem* __restrict__ items, float* __restrict__ P, Batch batch) {
+    A16 += blockIdx.y * batch.strideA;  // batched call: problem blockIdx.y of a strided batch
+    B16 += blockIdx.y * batch.strideB;
+    P += blockIdx.y * batch.strideP;
     constexpr uint32_t K = 32u * KS;
     constexpr uint32_t PC = 4u * KS;
     constexpr uint32_t SW = PC - 1u < 15u ? PC - 1u : 15u;
@@ -517,7 +530,10 @@ denseGroupsAnyK(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B
                 const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ groupRowBase,
                 const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
                 const uint8_t* __restrict__ blockMask, const DenseItem* __restrict__ items,
-                uint32_t numItems, float* __restrict__ P) {
+                uint32_t numItems, float* __restrict__ P, Batch batch) {
+    A16 += blockIdx.y * batch.strideA;  // batched call: problem blockIdx.y of a strided batch
+    B16 += blockIdx.y * batch.strideB;
+    P += blockIdx.y * batch.strideP;
     const uint32_t itemId = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
     if (itemId >= numItems) return;
     const DenseItem item = items[itemId];
@@ -573,7 +589,10 @@ denseGroupsCvt(const float* __restrict__ A, const float* __restrict__ B, uint32_
                const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ groupRowBase,
                const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
                const uint8_t* __restrict__ blockMask, const DenseItem* __restrict__ items,
-               uint32_t numItems, float* __restrict__ P) {
+               uint32_t numItems, float* __restrict__ P, Batch batch) {
+    A += blockIdx.y * batch.strideA;  // batched call: problem blockIdx.y of a strided batch
+    B += blockIdx.y * batch.strideB;
+    P += blockIdx.y * batch.strideP;
     const uint32_t itemId = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
     if (itemId >= numItems) return;
     const DenseItem item = items[itemId];
@@ -617,7 +636,10 @@ denseGroupsF32(const float* __restrict__ A, const float* __restrict__ B, uint32_
                const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ groupRowBase,
                const uint32_t* __restrict__ blockCols, const TileT* __restrict__ tiles,
                const uint8_t* __restrict__ blockMask, const DenseItem* __restrict__ items,
-               uint32_t numItems, float* __restrict__ P) {
+               uint32_t numItems, float* __restrict__ P, Batch batch) {
+    A += blockIdx.y * batch.strideA;  // batched call: problem blockIdx.y of a strided batch
+    B += blockIdx.y * batch.strideB;
+    P += blockIdx.y * batch.strideP;
     const uint32_t itemId = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
     if (itemId >= numItems) return;
     const DenseItem item = items[itemId];
@@ -664,7 +686,10 @@ __global__ void __launch_bounds__(kThreads)
 sparseEntries(const float* __restrict__ A, const float* __restrict__ B, uint32_t K,
               const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ entryCol,
               const uint32_t* __restrict__ entryDst, const uint8_t* __restrict__ entryRow,
-              const SparseItem* __restrict__ items, float* __restrict__ P) {
+              const SparseItem* __restrict__ items, float* __restrict__ P, Batch batch) {
+    A += blockIdx.y * batch.strideA;  // batched call: problem blockIdx.y of a strided batch
+    B += blockIdx.y * batch.strideB;
+    P += blockIdx.y * batch.strideP;
     extern __shared__ __attribute__((aligned(16))) float panelA[];
     const SparseItem item = items[xcdContiguous(blockIdx.x, gridDim.x)];
     const uint32_t chunks = K >> 2;  // float4 chunks per row
@@ -750,7 +775,10 @@ __global__ void __launch_bounds__(kThreads)
 sparseEntriesLowp(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, uint32_t K,
                   const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ entryCol,
                   const uint32_t* __restrict__ entryDst, const uint8_t* __restrict__ entryRow,
-                  const SparseItem* __restrict__ items, float* __restrict__ P) {
+                  const SparseItem* __restrict__ items, float* __restrict__ P, Batch batch) {
+    A16 += blockIdx.y * batch.strideA;  // batched call: problem blockIdx.y of a strided batch
+    B16 += blockIdx.y * batch.strideB;
+    P += blockIdx.y * batch.strideP;
     extern __shared__ __attribute__((aligned(16))) uint8_t panelA16[];
     const SparseItem item = items[xcdContiguous(blockIdx.x, gridDim.x)];
     const uint32_t chunks = K >> 3;  // 16-byte chunks (8 elements) per row
@@ -806,6 +834,29 @@ sparseEntriesLowp(const uint16_t* __restrict__ A16, const uint16_t* __restrict__
 #pragma unroll
         for (int off = LPE / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, LPE);
         if (live && t == 0) P[entryDst[idx]] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// batchedMatrixTranspose (reference src/sddmmKernel.cu:2486-2515): out[b][x][y] = in[b][y][x] for
+// `height` x `width` row-major matrices; 32 x 32 tiles through LDS (padded), 256 threads.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+batchedTranspose(const float* __restrict__ in, float* __restrict__ out, uint32_t width, uint32_t height) {
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * width * height;
+    const uint32_t x0 = blockIdx.x * 32u, y0 = blockIdx.y * 32u;
+    const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (uint32_t j = 0; j < 32; j += 8) {
+        const uint32_t x = x0 + tx, y = y0 + ty + j;
+        if (x < width && y < height) tile[ty + j][tx] = in[base + (size_t)y * width + x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 32; j += 8) {
+        const uint32_t x = y0 + tx, y = x0 + ty + j;  // coordinates in the transposed matrix (height wide)
+        if (x < height && y < width) out[base + (size_t)y * height + x] = tile[tx][ty + j];
     }
 }
 

@@ -89,6 +89,9 @@ HIP_SYMBOLS = {
     "bsmr_plan_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
     "bsmr_cluster_rows": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float,
                                     C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p]),
+    "bsmr_sddmm_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
+                                   C.c_void_p]),
+    "bsmr_batched_transpose": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsmr_plan_sparse_choice": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32),
                                           C.POINTER(C.c_uint32)]),
     "bsmr_plan_dense_choice": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
@@ -375,6 +378,14 @@ def sddmm_operator(csr: CSR, K: int, A, B, alpha=0.3, delta=0.3, mode=COMPUTE_F1
 # --- device entry points (pointers are integers, e.g. torch.Tensor.data_ptr()) ---
 def sddmm(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, mode=COMPUTE_F16, stream: int = 0):
     _check(hip().bsmr_sddmm(plan, K, A_ptr, B_ptr, P_ptr, mode, stream), "bsmr_sddmm")
+
+
+def sddmm_batch(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, num_batches: int, mode=COMPUTE_F16, stream: int = 0):
+    _check(hip().bsmr_sddmm_batch(plan, K, A_ptr, B_ptr, P_ptr, num_batches, mode, stream), "bsmr_sddmm_batch")
+
+
+def batched_transpose(width: int, height: int, num_batches: int, in_ptr: int, out_ptr: int, stream: int = 0):
+    _check(hip().bsmr_batched_transpose(width, height, num_batches, in_ptr, out_ptr, stream), "bsmr_batched_transpose")
 
 
 def sddmm_timed(plan, K, A_ptr, B_ptr, P_ptr, mode=COMPUTE_F16, stream=0, warmup=2, iters=20) -> dict:

@@ -169,6 +169,18 @@ int bsmr_sddmm_timed(bsmr_plan *plan, uint32_t K, const float *A_dev, const floa
                      float *P_dev, int compute_mode, void *stream, int warmup, int iters,
                      bsmr_timing *out);
 
+/* sddmm_gpu_batch (include/sddmmKernel.cuh:41-47, src/sddmmKernel.cu:2764-2869): num_batches
+ * independent problems over one sparsity plan, stored back to back - A: [b][M][K] row-major,
+ * B: [b][N][K] (each K x N column-major), P: [b][nnz].  One conversion pass over all batches, then
+ * the dense and residue kernels with the batch index in the grid's y dimension. */
+int bsmr_sddmm_batch(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev, float *P_dev,
+                     uint32_t num_batches, int compute_mode, void *stream);
+
+/* batchedMatrixTranspose (include/sddmmKernel.cuh:49-51, src/sddmmKernel.cu:2486-2515):
+ * out[b] = transpose(in[b]) for num_batches row-major height x width matrices. */
+int bsmr_batched_transpose(uint32_t width, uint32_t height, uint32_t num_batches, const float *in_dev,
+                           float *out_dev, void *stream);
+
 /* Convert fp32 operands once (mode F16 or BF16); A16_dev / B16_dev are M*K and
  * N*K 16-bit elements in the same layouts. */
 int bsmr_convert_operands(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev,

@@ -439,3 +439,45 @@ def test_medium_scale_properties(engine, oracle):
         pipe = check_case(engine, oracle, rows, cols, ro, ci, K, 0.3, delta, 0, row_mode=row_mode)
         st = pipe.plan_stats()
         assert st["num_dense_entries"] + st["num_sparse_entries"] == ci.size
+
+
+@pytest.mark.parametrize("K,delta,mode", [(32, 0.1, 0), (128, 0.0, 0), (128, 0.3, 1), (64, 0.1, 2), (96, 0.1, 0)])
+def test_batched_sddmm_equals_single_calls(engine, oracle, K, delta, mode):
+    """bsmr_sddmm_batch (sddmm_gpu_batch of the reference): num_batches problems over one plan, A / B / P
+    stored back to back; every batch equals the single call on its operands, bit for bit."""
+    rows, cols, ro, ci = synth.community_graph(n=260, avg_degree=36, communities=5, seed=K)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    pipe = engine.Pipeline(csr, alpha=0.2, delta=delta, device=0)
+    nb = 3
+    dev = _dev()
+    A = np.concatenate([engine.make_data(rows * K, 100 + b) for b in range(nb)])
+    B = np.concatenate([engine.make_data(cols * K, 200 + b) for b in range(nb)])
+    tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    tP = torch.full((nb * csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    engine.sddmm_batch(pipe.plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), nb, mode, s)
+    torch.cuda.synchronize()
+    got = tP.cpu().numpy().reshape(nb, csr.nnz)
+    assert not np.isnan(got).any()
+    for b in range(nb):
+        single = run_hip(engine, pipe, K, A[b * rows * K:(b + 1) * rows * K], B[b * cols * K:(b + 1) * cols * K], mode)
+        assert np.array_equal(got[b], single), f"batch {b}"
+        want = oracle.sddmm_cpu(rows, cols, K, ro, ci, A[b * rows * K:(b + 1) * rows * K], B[b * cols * K:(b + 1) * cols * K])
+        if not (mode == 1 and K < 512):
+            assert oracle.check_data(want, got[b])[0] == 0
+    # a later single call is not affected by the batch state
+    assert np.array_equal(run_hip(engine, pipe, K, A[:rows * K], B[:cols * K], mode), got[0])
+    assert engine.hip().bsmr_sddmm_batch(pipe.plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), 0, mode, None) == engine.OK
+    assert engine.hip().bsmr_sddmm_batch(pipe.plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), 70000, mode, None) \
+        == engine.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (32, 32, 2), (33, 65, 3), (100, 7, 4), (5, 300, 1)])
+def test_batched_transpose(engine, shape):
+    width, height, nb = shape
+    dev = _dev()
+    x = torch.arange(nb * width * height, dtype=torch.float32, device=dev).reshape(nb, height, width)
+    y = torch.full((nb, width, height), float("nan"), dtype=torch.float32, device=dev)
+    engine.batched_transpose(width, height, nb, x.data_ptr(), y.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(y, x.transpose(1, 2).contiguous())
