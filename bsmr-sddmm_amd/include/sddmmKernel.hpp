@@ -25,3 +25,13 @@ void sddmm_gpu(UIN M, UIN N, UIN K, const float* matrixA, const float* matrixB, 
 // a multiple of 32 through one path, so this forwards to sddmm_gpu.
 void sddmm_gpu_k32(UIN M, UIN N, UIN K, const float* matrixA, const float* matrixB,
                    const RPHM& rphm, float* matrixP, Logger& logger);
+
+// Batched form (include/sddmmKernel.cuh:41-47): numBatch problems over one plan, device operands
+// stored back to back (A: [b][M][K], B: [b][N][K], P: [b][nnz]); `time` receives ms per batched call.
+void sddmm_gpu_batch(const UIN numBatch, const UIN M, const UIN N, const UIN K, const UIN nnz,
+                     const float* matrixA, const float* matrixB, const RPHM& rphm, float* matrixP, float& time);
+
+// out[b] = transpose(in[b]) for numBatches row-major height x width device matrices
+// (include/sddmmKernel.cuh:49-51).
+void batchedMatrixTranspose(const UIN width, const UIN height, const UIN numBatches, const float* d_input,
+                            float* d_output);

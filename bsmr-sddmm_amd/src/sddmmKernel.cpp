@@ -2,6 +2,8 @@
 // sddmm_gpu_k32).  All device work happens behind include/bsmr_hip.h.
 #include "sddmmKernel.hpp"
 
+#include <chrono>
+
 #include <cstdio>
 
 #include "bsmr_hip.h"
@@ -69,4 +71,34 @@ void sddmm_gpu(const Matrix<float>& matrixA, const Matrix<float>& matrixB, const
     }
     sddmm_gpu(matrixP.row(), matrixP.col(), matrixA.col(), A.data(), B.data(), rphm, P.data(), logger);
     matrixP.setValues() = d2h(P);
+}
+
+void sddmm_gpu_batch(const UIN numBatch, const UIN M, const UIN N, const UIN K, const UIN nnz,
+                     const float* matrixA, const float* matrixB, const RPHM& rphm, float* matrixP, float& time) {
+    (void)M;
+    (void)N;
+    (void)nnz;
+    time = 0.0f;
+    if (!rphm.plan()) {
+        fprintf(stderr, "sddmm_gpu_batch: RPHM has no device plan (status %d: %s)\n", rphm.planStatus(),
+                bsmr_strerror(rphm.planStatus()));
+        return;
+    }
+    // one untimed call (allocates the operand workspace), then the timed one
+    int st = bsmr_sddmm_batch(rphm.plan(), K, matrixA, matrixB, matrixP, numBatch, g_computeMode, nullptr);
+    if (st == BSMR_OK) st = bsmr_device_synchronize(0);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (st == BSMR_OK) st = bsmr_sddmm_batch(rphm.plan(), K, matrixA, matrixB, matrixP, numBatch, g_computeMode, nullptr);
+    if (st == BSMR_OK) st = bsmr_device_synchronize(0);
+    if (st != BSMR_OK) {
+        fprintf(stderr, "sddmm_gpu_batch: %s (%s)\n", bsmr_strerror(st), bsmr_last_hip_error());
+        return;
+    }
+    time = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void batchedMatrixTranspose(const UIN width, const UIN height, const UIN numBatches, const float* d_input,
+                            float* d_output) {
+    const int st = bsmr_batched_transpose(width, height, numBatches, d_input, d_output, nullptr);
+    if (st != BSMR_OK) fprintf(stderr, "batchedMatrixTranspose: %s (%s)\n", bsmr_strerror(st), bsmr_last_hip_error());
 }
