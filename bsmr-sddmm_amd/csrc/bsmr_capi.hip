@@ -168,7 +168,12 @@ int uploadDense(DenseFormat& f, const bsmr::PackedPlan& pk, uint64_t& bytes) {
 
 // Dense format for a call with inner dimension K.
 const DenseFormat& chooseFormat(const bsmr_plan* p, uint32_t K) {
-    if (p->fmt[1].H && p->fmt[0].unionColumns * (uint64_t)K * 2ull >= kGroupedGatherBytes) return p->fmt[1];
+    // grouped when the ungrouped gather is large AND grouping at least halves it (measured at K = 512,
+    // ungrouped streaming kernel vs grouped: nips-like 1.94x fewer columns 31.7 vs 34.3 us, mycielskian15
+    // 1.6x 39.6 vs 57.4, 4096^2 Bernoulli(0.1) delta=0.1 2.09x 39.3 vs 35.1, delta=0 3.26x 62.4 vs 35.5)
+    if (p->fmt[1].H && p->fmt[0].unionColumns * (uint64_t)K * 2ull >= kGroupedGatherBytes &&
+        p->fmt[0].unionColumns >= 2 * p->fmt[1].unionColumns)
+        return p->fmt[1];
     return p->fmt[0];
 }
 
@@ -213,7 +218,7 @@ int launchStreamT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
     if (WAVES == bsmr::kWavesPerWG && f.streamWaves == 1)
         return launchStreamT<KS, MODE, TileT, 1>(f, A16, B16, tiles, P, s);
     auto kernel = bsmr::denseStream<KS, MODE, TileT, 8, WAVES>;
-    const size_t lds = (size_t)WAVES * bsmr::streamSlots(KS) * 1024u * KS;  // wave-private ring
+    const size_t lds = (size_t)WAVES * bsmr::streamSlots(KS) * 1024u * (KS > 8 ? 8 : KS);  // wave-private ring of images
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         BSMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),

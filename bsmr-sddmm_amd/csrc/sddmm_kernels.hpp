@@ -409,10 +409,14 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     B16 += blockIdx.y * batch.strideB;
     P += blockIdx.y * batch.strideP;
     constexpr uint32_t K = 32u * KS;
-    constexpr uint32_t PC = 4u * KS;
+    // A block is gathered as SPLIT images of KSL 32-wide k steps each (K = 512: two images of 8 KB), so
+    // that a wave's ring stays at 16 KB and ten waves fit a CU; the accumulator carries over the images.
+    constexpr uint32_t KSL = KS > 8 ? 8u : (uint32_t)KS;
+    constexpr uint32_t SPLIT = (uint32_t)KS / KSL;
+    constexpr uint32_t PC = 4u * KSL;                 // 16-byte pieces per column of an image
     constexpr uint32_t SW = PC - 1u < 15u ? PC - 1u : 15u;
-    constexpr uint32_t rowBytes = 2u * K;
-    constexpr uint32_t blkBytes = 16u * rowBytes;
+    constexpr uint32_t rowBytes = 64u * KSL;          // one column of an image
+    constexpr uint32_t blkBytes = 16u * rowBytes;     // one image
     constexpr bool WINDOWED = sizeof(TileT) == 1;
     constexpr uint32_t CREG = (MAXB + 3) / 4;
     constexpr uint32_t SLOTS = streamSlots(KS);
@@ -445,27 +449,27 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     asm volatile("" : "+v"(myRow));
     // ring of SLOTS block images per wave: SLOTS-1 gathers stay in flight (a gather takes
     // ~1200 cycles under load, a block's MFMAs ~400: measured with in-kernel stamps)
-    auto gather = [&](uint32_t m) {  // my block m -> slot m % SLOTS
-        uint8_t* dst = myLds + (m % SLOTS) * blkBytes;
+    auto gather = [&](uint32_t u) {  // image u = (my block u / SPLIT, k range u % SPLIT) -> slot u % SLOTS
+        const uint32_t m = u / SPLIT, h = u % SPLIT;
+        uint8_t* dst = myLds + (u % SLOTS) * blkBytes;
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
+        for (int j = 0; j < (int)KSL; ++j) {
             const uint32_t f = 64u * j + lane;
             const uint32_t col = f / PC, t = f % PC;
             const uint32_t cid = __shfl(cols[m >> 2], ((m & 3u) << 4) + col);
-            const uint16_t* src = B16 + (size_t)cid * K + ((t ^ (col & SW)) << 3);
+            const uint16_t* src = B16 + (size_t)cid * K + h * (32u * KSL) + ((t ^ (col & SW)) << 3);
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)src,
                 (__attribute__((address_space(3))) void*)(dst + j * 1024u), 16, 0, 0);
         }
     };
-    auto waitInFlight = [&](uint32_t blocks) {  // all but the youngest `blocks` gathers have landed
-        if (blocks == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (blocks * KS == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else if (blocks * KS == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (blocks * KS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (blocks * KS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (blocks * KS == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    auto waitInFlight = [&](uint32_t images) {  // all but the youngest `images` gathers have landed
+        if (images == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (images * KSL == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (images * KSL == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (images * KSL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (images * KSL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     };
 
     // 2. first gather, then the A fragments, destinations and row bases, then the second gather: all
@@ -489,31 +493,36 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         rowBase[i] = WINDOWED ? rowBaseTable[(size_t)itemId * 16u + 4u * g + i] : rowBaseTable[rowSlot + 4u * g + i];
+    const uint32_t units = myCount * SPLIT;
 #pragma unroll
-    for (uint32_t m = 1; m + 1 < SLOTS; ++m)
-        if (m < myCount) gather(m);
+    for (uint32_t u = 1; u + 1 < SLOTS; ++u)
+        if (u < units) gather(u);
 #pragma unroll
     for (uint32_t m = 0; m < (uint32_t)MAXB; ++m) {
         if (m >= myCount) break;  // wave-uniform
-        // slot (m + SLOTS - 1) % SLOTS held block m-1, whose reads returned before its MFMAs
-        if (m + SLOTS - 1 < myCount) gather(m + SLOTS - 1);
-        const uint32_t younger = min(myCount - 1u - m, SLOTS - 1u);  // gathers issued after block m's
-        if (younger == 0) waitInFlight(0);
-        else if (younger == 1) waitInFlight(1);
-        else waitInFlight(2);
-        if (m == 0) {  // the A fragments have landed with the first block
-#pragma unroll
-            for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[s]));
-        }
-        const uint8_t* bCol = myLds + (m % SLOTS) * blkBytes + r * rowBytes;
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const u32x4 bv = *reinterpret_cast<const u32x4*>(bCol + (((4u * s + g) ^ (r & SW)) << 4));
-            c = mfma16<MODE>(a[s], bv, c);
+        for (uint32_t h = 0; h < SPLIT; ++h) {
+            const uint32_t u = m * SPLIT + h;
+            // slot (u + SLOTS - 1) % SLOTS held image u-1, whose reads returned before its MFMAs
+            if (u + SLOTS - 1 < units) gather(u + SLOTS - 1);
+            const uint32_t younger = min(units - 1u - u, SLOTS - 1u);  // gathers issued after image u's
+            if (younger == 0) waitInFlight(0);
+            else if (younger == 1) waitInFlight(1);
+            else waitInFlight(2);
+            if (u == 0) {  // the A fragments have landed with the first image
+#pragma unroll
+                for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[s]));
+            }
+            const uint8_t* bCol = myLds + (u % SLOTS) * blkBytes + r * rowBytes;
+#pragma unroll
+            for (int s = 0; s < (int)KSL; ++s) {
+                const u32x4 bv = *reinterpret_cast<const u32x4*>(bCol + (((4u * s + g) ^ (r & SW)) << 4));
+                c = mfma16<MODE>(a[h * KSL + s], bv, c);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         acc[m] = c;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 #pragma unroll
     for (uint32_t m = 0; m < (uint32_t)MAXB; ++m)

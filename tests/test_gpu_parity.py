@@ -177,7 +177,7 @@ def test_plan_knobs(engine, oracle, monkeypatch, knobs, K):
 
 def test_grouped_format_is_chosen_for_gather_bound_calls(engine, oracle):
     """A plan keeps a second dense format (4 panels per group) and uses it when the ungrouped
-    B gather would exceed ~200 MB; both formats give the same entries."""
+    B gather would exceed ~200 MB and grouping at least halves it; both formats give the same entries."""
     rows, cols, ro, ci = synth.bernoulli(rows=1024, cols=4096, density=0.1, seed=4)
     csr = engine.CSR.from_arrays(rows, cols, ro, ci)
     pipe = engine.Pipeline(csr, alpha=0.3, delta=0.0, device=0)
