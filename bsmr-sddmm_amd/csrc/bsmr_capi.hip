@@ -76,6 +76,7 @@ struct bsmr_plan {
     int sparseLpe = 0;             // 0 = per-K tuned shape (sparseShape); BSMR_SPARSE_LPE = 4 / 8 / 16 forces the run-time loop
     bool sparseLowp = true;        // residue from the fp16/bf16 copies whenever the conversion pass runs (BSMR_SPARSE_LOWP=0: always fp32)
     bool convertInKernel = false;  // dense part so small that the full operand conversion pass does not pay
+    bool convertPass = false;      // F16/BF16 calls start with the fp32 -> 16-bit pass over A and B
     int denseBatch = 0;            // blocks per LDS batch at K = 128 (0 = default)
     bool useStream = true;         // streaming kernel for ungrouped plans (BSMR_DENSE_STREAM=0 disables)
 };
@@ -426,7 +427,7 @@ int checkCall(const bsmr_plan* p, uint32_t K, const void* A, const void* B, cons
 }
 
 inline bool needsWorkspace(const bsmr_plan* p, int mode) {
-    return mode != BSMR_COMPUTE_F32 && p->fmt[0].numItems && !p->convertInKernel;
+    return mode != BSMR_COMPUTE_F32 && p->convertPass;
 }
 
 int reserve(bsmr_plan* p, uint32_t K) {
@@ -453,13 +454,13 @@ int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P
             st = mode == BSMR_COMPUTE_F16 ? launchDenseCvt<0>(p, K, A, B, P, s) : launchDenseCvt<1>(p, K, A, B, P, s);
             if (st != BSMR_OK) return st;
         }
-    } else if (p->fmt[0].numItems) {
+    } else if (p->convertPass) {
         if (which & 1) {
             st = mode == BSMR_COMPUTE_F16 ? launchConvert<0>(p, K, A, B, p->A16, p->B16, s)
                                           : launchConvert<1>(p, K, A, B, p->A16, p->B16, s);
             if (st != BSMR_OK) return st;
         }
-        if (which & 2) {
+        if ((which & 2) && p->fmt[0].numItems) {
             st = mode == BSMR_COMPUTE_F16 ? launchDense16<0>(p, K, p->A16, p->B16, P, s)
                                           : launchDense16<1>(p, K, p->A16, p->B16, P, s);
             if (st != BSMR_OK) return st;
@@ -637,7 +638,12 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         // full conversion moves 6 bytes per operand element; the in-kernel path reads each
         // gathered element as fp32 (4 B, A re-read per block) from a slower kernel
         const int cvt = envInt("BSMR_CONVERT_IN_KERNEL", -1);
-        p->convertInKernel = cvt >= 0 ? cvt != 0 : pk.unionColumns * 16ull < ((uint64_t)d->M + d->N) * 6ull;
+        // a residue this large pays for the conversion pass by itself: it then reads 2 instead of 4 bytes
+        // per operand element (4096^2 Bernoulli(0.1), K = 512, all sparse: 176 -> 97 us)
+        const bool bigResidue = p->sparseLowp && pk.numSparseEntries > 10ull * ((uint64_t)d->M + d->N);
+        p->convertInKernel =
+            cvt >= 0 ? cvt != 0 : (!bigResidue && pk.unionColumns * 16ull < ((uint64_t)d->M + d->N) * 6ull);
+        p->convertPass = !p->convertInKernel && (pk.numBlocks != 0 || bigResidue);
 
         st = uploadDense(p->fmt[0], pk, p->indexBytes);
         p->fmt[0].stageInLds = outputMode == 2;
@@ -696,7 +702,7 @@ int bsmr_plan_get_stats(const bsmr_plan* p, bsmr_plan_stats* out) {
     out->grouped_group_size = p->fmt[1].H;
     out->grouped_dense_tiles = p->fmt[1].numTiles;
     out->grouped_union_columns = p->fmt[1].unionColumns;
-    out->sparse_lowp = p->sparseLowp && f.numItems && !p->convertInKernel && p->numSparseItems ? 1 : 0;
+    out->sparse_lowp = p->sparseLowp && p->convertPass && p->numSparseItems ? 1 : 0;
     return BSMR_OK;
 }
 
@@ -714,8 +720,7 @@ int bsmr_plan_sparse_choice(const bsmr_plan* plan, uint32_t K, int mode, uint32_
                             uint32_t* low_precision) {
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
-    const bool lowp = mode != BSMR_COMPUTE_F32 && plan->sparseLowp && plan->fmt[0].numItems &&
-                      !plan->convertInKernel && plan->numSparseItems;
+    const bool lowp = mode != BSMR_COMPUTE_F32 && plan->sparseLowp && plan->convertPass && plan->numSparseItems;
     if (lanes_per_entry) *lanes_per_entry = (uint32_t)sparseShape(plan, K, lowp).lpe;
     if (low_precision) *low_precision = lowp ? 1u : 0u;
     return BSMR_OK;
@@ -725,7 +730,7 @@ int bsmr_plan_reserve(bsmr_plan* plan, uint32_t K) {
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     BSMR_HIP(hipSetDevice(plan->device));
-    if (!plan->fmt[0].numItems || plan->convertInKernel) return BSMR_OK;
+    if (!plan->convertPass) return BSMR_OK;
     return reserve(plan, K);
 }
 
@@ -789,7 +794,7 @@ int bsmr_sddmm_lowp(bsmr_plan* plan, uint32_t K, const void* A16, const void* B1
     if (!plan || !A16 || !B16 || !P) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     if (mode != BSMR_COMPUTE_F16 && mode != BSMR_COMPUTE_BF16) return BSMR_ERR_INVALID_ARG;
-    const bool residueLowp = plan->sparseLowp && plan->fmt[0].numItems && !plan->convertInKernel;
+    const bool residueLowp = plan->sparseLowp && plan->convertPass;
     if (plan->numSparseItems && !residueLowp && (!A || !B)) return BSMR_ERR_INVALID_ARG;  // fp32 residue
     BSMR_HIP(hipSetDevice(plan->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
