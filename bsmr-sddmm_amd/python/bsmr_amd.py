@@ -50,7 +50,8 @@ class PlanStats(C.Structure):
                 ("device_index_bytes", C.c_uint64), ("group_size", C.c_uint32),
                 ("num_dense_tiles", C.c_uint64), ("union_columns", C.c_uint64),
                 ("grouped_group_size", C.c_uint32), ("grouped_dense_tiles", C.c_uint64),
-                ("grouped_union_columns", C.c_uint64), ("sparse_lowp", C.c_uint64)]
+                ("grouped_union_columns", C.c_uint64), ("sparse_lowp", C.c_uint64),
+                ("folded_dense_entries", C.c_uint64)]
 
 
 class ReorderingReport(C.Structure):

@@ -9,6 +9,9 @@ sys.path.insert(0, str(REPO / "bsmr-sddmm_amd" / "python"))
 import hostinfo  # noqa: E402
 
 hostinfo.limit_openmp_threads()   # before any OpenMP runtime starts: honour the container's CPU quota
+# Plans fold a dense part of < 32768 entries into the residue; the test matrices are that small, and the
+# dense kernels are what most tests are about.  test_small_dense_parts_are_folded covers the default.
+os.environ.setdefault("BSMR_FOLD_DENSE_BELOW", "0")
 
 import numpy as np  # noqa: E402
 import pytest  # noqa: E402

@@ -37,6 +37,8 @@ def run_hip(eng, pipe, K, A, B, mode):
 def dense_flags(pipe):
     """1 for CSR entries computed by the dense-block path, 0 for the sparse residue."""
     flags = np.zeros(pipe.csr.nnz, dtype=np.uint8)
+    if pipe.plan_stats()["folded_dense_entries"]:
+        return flags                       # a small dense part is computed with the residue
     bv = pipe.array("blockValues")
     flags[bv[bv != 0xFFFFFFFF]] = 1
     return flags
@@ -481,3 +483,21 @@ def test_batched_transpose(engine, shape):
     engine.batched_transpose(width, height, nb, x.data_ptr(), y.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(y, x.transpose(1, 2).contiguous())
+
+
+def test_small_dense_parts_are_folded(engine, oracle, monkeypatch):
+    """Default plans compute a dense part of fewer than 32768 entries with the residue (one launch less):
+    same entries, same destinations; above the threshold the dense kernels run."""
+    monkeypatch.delenv("BSMR_FOLD_DENSE_BELOW", raising=False)
+    rows, cols, ro, ci = synth.community_graph(n=400, avg_degree=40, communities=6, seed=3)
+    for K, mode in ((32, 0), (128, 0), (128, 2)):
+        pipe = check_case(engine, oracle, rows, cols, ro, ci, K, 0.2, 0.1, mode)
+        st = pipe.plan_stats()
+        dense_in_rphm = int((pipe.array("blockValues") != 0xFFFFFFFF).sum())
+        assert 0 < dense_in_rphm < 32768
+        assert st["folded_dense_entries"] == dense_in_rphm
+        assert st["num_dense_entries"] == 0 and st["num_sparse_entries"] == pipe.csr.nnz
+        assert st["dense_work_items"] == 0
+    monkeypatch.setenv("BSMR_FOLD_DENSE_BELOW", "100")
+    pipe = check_case(engine, oracle, rows, cols, ro, ci, 64, 0.2, 0.1, 0)
+    assert pipe.plan_stats()["folded_dense_entries"] == 0 and pipe.plan_stats()["num_dense_entries"] == dense_in_rphm
