@@ -76,6 +76,8 @@ struct bsmr_plan {
     int sparseLpe = 0;             // 0 = per-K tuned shape (sparseShape); BSMR_SPARSE_LPE = 4 / 8 / 16 forces the run-time loop
     bool sparseLowp = true;        // residue from the fp16/bf16 copies whenever the conversion pass runs (BSMR_SPARSE_LOWP=0: always fp32)
     bool convertInKernel = false;  // dense part so small that the full operand conversion pass does not pay
+    uint32_t* entryRowId = nullptr;  // free-form residue: row id per entry (panelRows / entryRow unused)
+    bool sparseFree = false;
     uint64_t foldedEntries = 0;    // entries of a small dense part that were moved to the residue
     bool convertPass = false;      // F16/BF16 calls start with the fp32 -> 16-bit pass over A and B
     int denseBatch = 0;            // blocks per LDS batch at K = 128 (0 = default)
@@ -142,7 +144,7 @@ void freePlanDevice(bsmr_plan* p) {
             if (q) (void)hipFree(q);
         f = DenseFormat{};
     }
-    void* ptrs[] = {p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, p->A16, p->B16};
+    void* ptrs[] = {p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->entryRowId, p->sparseItems, p->A16, p->B16};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
 }
@@ -359,7 +361,10 @@ template <int LPE, int CPL>
 int launchSparseT(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, hipStream_t s) {
     const size_t lds = (size_t)16 * (K + bsmr::kSparseLdsPad) * sizeof(float);
     const uint32_t wgs = p->numSparseItems;  // no padding: every workgroup reads its item
-    if (lds <= 64 * 1024) {
+    if (p->sparseFree) {
+        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, false, CPL, true>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s,
+                           A, B, K, p->entryRowId, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, g_batch);
+    } else if (lds <= 64 * 1024) {
         hipLaunchKernelGGL((bsmr::sparseEntries<LPE, true, CPL>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), lds, s, A, B,
                            K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, g_batch);
     } else {
@@ -390,7 +395,11 @@ int launchSparse16T(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const u
                     hipStream_t s) {
     const size_t lds = (size_t)16 * (2u * K + bsmr::kSparseLdsPad16);
     const uint32_t wgs = p->numSparseItems;
-    if (lds <= 64 * 1024) {
+    if (p->sparseFree) {
+        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, false, CPL, true>), dim3(wgs, g_batch.count),
+                           dim3(bsmr::kThreads), 0, s, A16, B16, K, p->entryRowId, p->entryCol, p->entryDst, p->entryRow,
+                           p->sparseItems, P, g_batch);
+    } else if (lds <= 64 * 1024) {
         hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, true, CPL>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), lds, s,
                            A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, g_batch);
     } else {
@@ -661,6 +670,7 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         opt.sparsePerItem = envInt("BSMR_SPARSE_ENTRIES_PER_WG", 256);
         opt.forceWideTiles = envInt("BSMR_FORCE_TILE32", 0) != 0;
         opt.columnOrder = envInt("BSMR_COLUMN_ORDER", 1) != 0;
+        opt.freeResidue = envInt("BSMR_FREE_RESIDUE", 0);
         // 0 = 16/32-bit offsets from the row's first dense entry; 1 = 8-bit window offsets,
         // scattered; 2 = 8-bit window offsets, assembled in LDS and stored coalesced
         const int outputMode = envInt("BSMR_OUTPUT_MODE", 1);
@@ -702,6 +712,8 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         if (st == BSMR_OK) st = upload(p->entryCol, pk.entryCol, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->entryDst, pk.entryDst, p->indexBytes);
         if (st == BSMR_OK) st = upload(p->entryRow, pk.entryRow, p->indexBytes);
+        if (st == BSMR_OK) st = upload(p->entryRowId, pk.entryRowId, p->indexBytes);
+        p->sparseFree = pk.freeResidue;
         if (st == BSMR_OK) st = upload(p->sparseItems, pk.sparseItems, p->indexBytes);
 
         // second dense format (4 panels per group) for gather-bound calls
@@ -754,6 +766,7 @@ int bsmr_plan_get_stats(const bsmr_plan* p, bsmr_plan_stats* out) {
     out->grouped_union_columns = p->fmt[1].unionColumns;
     out->sparse_lowp = p->sparseLowp && p->convertPass && p->numSparseItems ? 1 : 0;
     out->folded_dense_entries = p->foldedEntries;
+    out->free_residue = p->sparseFree ? 1 : 0;
     return BSMR_OK;
 }
 

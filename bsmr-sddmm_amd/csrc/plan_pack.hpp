@@ -46,6 +46,7 @@ struct PackOptions {
     bool forceWideTiles = false;
     bool columnOrder = true;  // blocks in column-id order, items sorted by first column
     bool staged = true;       // try the staged (LDS window) destination encoding
+    int freeResidue = 0;      // 1: residue in global column order instead of per panel (cross-check only)
 };
 
 struct PackedPlan {
@@ -64,7 +65,9 @@ struct PackedPlan {
     std::vector<uint8_t> blockMask;       // [NB]
     std::vector<DenseItem> denseItems;
     std::vector<uint32_t> entryCol, entryDst;
-    std::vector<uint8_t> entryRow;
+    std::vector<uint8_t> entryRow;        // row inside the panel (panel form)
+    std::vector<uint32_t> entryRowId;     // row id (free form: entries in global column order, no panels)
+    bool freeResidue = false;
     std::vector<SparseItem> sparseItems;
     uint64_t numBlocks = 0, numTiles = 0, numDenseEntries = 0, numSparseEntries = 0;
     uint64_t unionColumns = 0;            // sum over groups of distinct dense columns
@@ -410,9 +413,46 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
         for (uint32_t s = d->sparse_value_offsets[p]; s < d->sparse_value_offsets[p + 1]; s += perWG)
             out.sparseItems.push_back(
                 SparseItem{p, s, std::min<uint32_t>(perWG, d->sparse_value_offsets[p + 1] - s), 0});
+    // Free form (opt-in, BSMR_FREE_RESIDUE=1): no panels - entries in global (column, row) order, both
+    // operands gathered per entry.  Measured against the panel form with items in median-column order it
+    // loses everywhere (cop20k-like 54 vs 50 us, mycielskian15 88 vs 69, 4096^2 Bernoulli all-sparse
+    // K=512 117 vs 81), so it is never chosen automatically; it stays as a cross-check of the panel form.
+    if (numSparse && opt.freeResidue > 0) {
+        std::vector<uint32_t> order(numSparse), rowId(numSparse);
+        for (uint32_t q = 0; q < P; ++q)
+            for (uint32_t i = d->sparse_value_offsets[q]; i < d->sparse_value_offsets[q + 1]; ++i)
+                rowId[i] = out.panelRows[(size_t)q * 16 + out.entryRow[i]];
+        for (uint64_t i = 0; i < numSparse; ++i) order[i] = (uint32_t)i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            return out.entryCol[a] != out.entryCol[b] ? out.entryCol[a] < out.entryCol[b] : rowId[a] < rowId[b];
+        });
+        const bool useFree = opt.freeResidue > 0;
+        if (useFree) {
+            std::vector<uint32_t> col(numSparse), dst(numSparse);
+            out.entryRowId.resize(numSparse);
+            for (uint64_t i = 0; i < numSparse; ++i) {
+                col[i] = out.entryCol[order[i]];
+                dst[i] = out.entryDst[order[i]];
+                out.entryRowId[i] = rowId[order[i]];
+            }
+            out.entryCol.swap(col);
+            out.entryDst.swap(dst);
+            out.entryRow.clear();
+            out.freeResidue = true;
+            out.sparseItems.clear();
+            for (uint64_t s0 = 0; s0 < numSparse; s0 += perWG)
+                out.sparseItems.push_back(
+                    SparseItem{0xFFFFFFFFu, (uint32_t)s0, (uint32_t)std::min<uint64_t>(perWG, numSparse - s0), 0});
+            return BSMR_OK;
+        }
+    }
+    // launch order = order of the items' median column: consecutive items, which share an XCD and run at
+    // about the same time, then read neighbouring columns of B (banded / mesh matrices: the XCD's L2 works
+    // as a sliding window).  The median, not the first column: a few far-away entries per panel would
+    // otherwise decide the order (cop20k-like K=128: L2 hit rate 22 % with the first column as key).
     if (opt.columnOrder)
         std::stable_sort(out.sparseItems.begin(), out.sparseItems.end(), [&](const SparseItem& a, const SparseItem& b) {
-            return out.entryCol[a.start] < out.entryCol[b.start];
+            return out.entryCol[a.start + a.count / 2] < out.entryCol[b.start + b.count / 2];
         });
     return BSMR_OK;
 }

@@ -690,7 +690,9 @@ constexpr int kSparseLdsPad = 4;  // floats
 
 // CPL > 0: K = 4 * LPE * CPL, every lane's CPL column chunks are requested before the first
 // is used (the residue is a gather: what matters is bytes in flight); CPL = 0: any K.
-template <int LPE, bool A_IN_LDS, int CPL = 0>
+// FREE: the residue in global (column, row) order - no panels; `panelRows` then holds one row id per entry
+// and A rows are gathered like B columns (plan_pack.hpp, "Panel form or free form?").
+template <int LPE, bool A_IN_LDS, int CPL = 0, bool FREE = false>
 __global__ void __launch_bounds__(kThreads)
 sparseEntries(const float* __restrict__ A, const float* __restrict__ B, uint32_t K,
               const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ entryCol,
@@ -725,10 +727,11 @@ sparseEntries(const float* __restrict__ A, const float* __restrict__ B, uint32_t
         const bool live = e < item.count;
         const uint32_t idx = item.start + (live ? e : 0u);
         const uint32_t col = entryCol[idx];
-        const uint32_t row = entryRow[idx];
+        const uint32_t row = FREE ? panelRows[idx] : (uint32_t)entryRow[idx];
         const float* bCol = B + (size_t)col * K;
-        const float* aRow = A_IN_LDS ? panelA + row * ldsStride
-                                     : A + (size_t)panelRows[item.panel * 16u + row] * K;
+        const float* aRow = FREE       ? A + (size_t)row * K
+                            : A_IN_LDS ? panelA + row * ldsStride
+                                       : A + (size_t)panelRows[item.panel * 16u + row] * K;
         float acc = 0.f;
         if constexpr (CPL > 0) {
             f32x4 bv[CPL];
@@ -779,7 +782,7 @@ __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
     }
 }
 
-template <int LPE, int MODE, bool A_IN_LDS, int CPL = 0>
+template <int LPE, int MODE, bool A_IN_LDS, int CPL = 0, bool FREE = false>
 __global__ void __launch_bounds__(kThreads)
 sparseEntriesLowp(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, uint32_t K,
                   const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ entryCol,
@@ -812,11 +815,12 @@ sparseEntriesLowp(const uint16_t* __restrict__ A16, const uint16_t* __restrict__
         const bool live = e < item.count;
         const uint32_t idx = item.start + (live ? e : 0u);
         const uint32_t col = entryCol[idx];
-        const uint32_t row = entryRow[idx];
+        const uint32_t row = FREE ? panelRows[idx] : (uint32_t)entryRow[idx];
         const uint16_t* bCol = B16 + (size_t)col * K;
-        const uint8_t* aRow = A_IN_LDS
-                                  ? panelA16 + row * ldsStride
-                                  : reinterpret_cast<const uint8_t*>(A16 + (size_t)panelRows[item.panel * 16u + row] * K);
+        const uint8_t* aRow =
+            FREE       ? reinterpret_cast<const uint8_t*>(A16 + (size_t)row * K)
+            : A_IN_LDS ? panelA16 + row * ldsStride
+                       : reinterpret_cast<const uint8_t*>(A16 + (size_t)panelRows[item.panel * 16u + row] * K);
         float acc = 0.f;
         if constexpr (CPL > 0) {  // K = 8 * LPE * CPL
             u32x4 bv[CPL];

@@ -51,7 +51,7 @@ class PlanStats(C.Structure):
                 ("num_dense_tiles", C.c_uint64), ("union_columns", C.c_uint64),
                 ("grouped_group_size", C.c_uint32), ("grouped_dense_tiles", C.c_uint64),
                 ("grouped_union_columns", C.c_uint64), ("sparse_lowp", C.c_uint64),
-                ("folded_dense_entries", C.c_uint64)]
+                ("folded_dense_entries", C.c_uint64), ("free_residue", C.c_uint64)]
 
 
 class ReorderingReport(C.Structure):

@@ -92,6 +92,7 @@ typedef struct bsmr_plan_stats {
     uint64_t grouped_union_columns;
     uint64_t sparse_lowp;             /* 1: in the F16/BF16 modes the residue reads the converted operands too */
     uint64_t folded_dense_entries;    /* entries of a small dense part (RPHM) that the plan computes with the residue */
+    uint64_t free_residue;            /* 1: residue entries run in global column order, not per panel */
 } bsmr_plan_stats;
 
 /* Kernel timings of the last bsmr_sddmm_timed call, milliseconds per iteration. */

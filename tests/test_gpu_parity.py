@@ -141,6 +141,7 @@ def test_large_k_sparse_without_lds(engine, oracle):
     {"BSMR_DENSE_BLOCKS_PER_WG": "1"}, {"BSMR_DENSE_BLOCKS_PER_WG": "5", "BSMR_DENSE_GROUP": "2"},
     {"BSMR_STREAM_WAVES": "4"}, {"BSMR_STREAM_WAVES": "4", "BSMR_DENSE_BLOCKS_PER_WG": "13"},
     {"BSMR_DENSE_BLOCKS_PER_WG": "8"}, {"BSMR_DENSE_BLOCKS_PER_WG": "32"},
+    {"BSMR_FREE_RESIDUE": "1"}, {"BSMR_FREE_RESIDUE": "1", "BSMR_SPARSE_LOWP": "0"}, {"BSMR_FREE_RESIDUE": "0"},
 ])
 @pytest.mark.parametrize("K", [32, 128, 512])
 def test_plan_knobs(engine, oracle, monkeypatch, knobs, K):
@@ -501,3 +502,19 @@ def test_small_dense_parts_are_folded(engine, oracle, monkeypatch):
     monkeypatch.setenv("BSMR_FOLD_DENSE_BELOW", "100")
     pipe = check_case(engine, oracle, rows, cols, ro, ci, 64, 0.2, 0.1, 0)
     assert pipe.plan_stats()["folded_dense_entries"] == 0 and pipe.plan_stats()["num_dense_entries"] == dense_in_rphm
+
+
+def test_free_form_residue_equals_panel_form(engine, oracle, monkeypatch):
+    """BSMR_FREE_RESIDUE=1 runs the residue without panels (entries in global column order, both operands
+    gathered): a cross-check of the panel form - same values, bit for bit in fp32 (mesh-like matrix)."""
+    rows, cols, ro, ci = synth.banded_mesh_like(n=20000, nnz=220000, seed=7)
+    K = 64
+    ref_pipe = check_case(engine, oracle, rows, cols, ro, ci, K, 0.3, 0.3, 0)
+    assert ref_pipe.plan_stats()["free_residue"] == 0
+    A = engine.make_data(rows * K, 5489)
+    B = engine.make_data(cols * K, 5490)
+    want = run_hip(engine, ref_pipe, K, A, B, 0)
+    monkeypatch.setenv("BSMR_FREE_RESIDUE", "1")
+    pipe = check_case(engine, oracle, rows, cols, ro, ci, K, 0.3, 0.3, 0)
+    assert pipe.plan_stats()["free_residue"] == 1
+    assert np.array_equal(run_hip(engine, pipe, K, A, B, 0), want)
