@@ -17,6 +17,11 @@
  *                           (src/sddmmKernel.cu:2561-2565,2650-2653)
  *   bsmr_sddmm_host      <- sddmm_gpu(Matrix A, Matrix B, rphm, CSR P, logger)
  *                           (src/sddmmKernel.cu:2518-2538): host operands in, host P out
+ *   bsmr_sddmm_batch / bsmr_batched_transpose
+ *                        <- sddmm_gpu_batch / batchedMatrixTranspose (include/sddmmKernel.cuh:41-51,
+ *                           src/sddmmKernel.cu:2764-2869, 2486-2515)
+ *   bsmr_cluster_rows    <- bsa_rowReordering_gpu (src/rowReordering.cu:1027-1095): the row
+ *                           clustering on the device, same row order and cluster count
  *   bsmr_convert_operands / bsmr_sddmm_lowp
  *                        <- no reference counterpart (the reference converts to
  *                           TF32 in registers); lets a caller that already holds
