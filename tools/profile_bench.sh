@@ -5,7 +5,7 @@ set -o pipefail
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
 # the row clustering is not what is profiled here: keep its thousands of pass launches out of the traces
 export BSMR_CLUSTER=host
