@@ -216,12 +216,14 @@ int launchGroupsT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
 }
 
 // streaming form for ungrouped plans whose items hold <= 32 blocks (8 per wave)
-template <int KS, int MODE, typename TileT, int WAVES = bsmr::kWavesPerWG>
+template <int KS, int MODE, typename TileT, int WAVES = bsmr::kWavesPerWG, int H = 1>
 int launchStreamT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, const TileT* tiles, float* P,
                   hipStream_t s) {
-    if (WAVES == bsmr::kWavesPerWG && f.streamWaves == 1)
-        return launchStreamT<KS, MODE, TileT, 1>(f, A16, B16, tiles, P, s);
-    auto kernel = bsmr::denseStream<KS, MODE, TileT, 8, WAVES>;
+    if (WAVES == bsmr::kWavesPerWG && f.streamWaves == 1) {
+        if (f.H == 2) return launchStreamT<KS, MODE, TileT, 1, 2>(f, A16, B16, tiles, P, s);
+        return launchStreamT<KS, MODE, TileT, 1, 1>(f, A16, B16, tiles, P, s);
+    }
+    auto kernel = bsmr::denseStream<KS, MODE, TileT, 8, WAVES, H>;
     const size_t lds = (size_t)WAVES * bsmr::streamSlots(KS) * 1024u * (KS > 8 ? 8 : KS);  // wave-private ring of images
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
@@ -265,7 +267,7 @@ int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uin
                   hipStream_t s) {
     const DenseFormat& f = chooseFormat(p, K);
     if (f.numItems == 0) return BSMR_OK;
-    if (f.H == 1 && f.maxItemBlocks <= 32 && !f.stageInLds && p->useStream) {
+    if ((f.H == 1 || (f.H == 2 && f.streamWaves == 1)) && f.maxItemBlocks <= 32 && !f.stageInLds && p->useStream) {
         switch (K) {
         case 32: return launchStream<1, MODE>(f, A16, B16, P, s);
         case 64: return launchStream<2, MODE>(f, A16, B16, P, s);

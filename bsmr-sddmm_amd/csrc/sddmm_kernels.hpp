@@ -399,7 +399,9 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
 // throughput, not by the latency of one gather, so the smaller footprint is kept.
 constexpr uint32_t streamSlots(int /*KS*/) { return 2u; }
 
-template <int KS, int MODE, typename TileT, int MAXB = 8, int WAVES = kWavesPerWG>
+// H > 1 (one-wave form only): the wave computes H consecutive panels of a row group for every block it
+// gathers - one LDS read of a B fragment feeds H MFMAs, and the group's union of columns is gathered once.
+template <int KS, int MODE, typename TileT, int MAXB = 8, int WAVES = kWavesPerWG, int H = 1>
 __global__ void __launch_bounds__(WAVES * kWave)
 denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
             const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ rowBaseTable,
@@ -441,12 +443,16 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
 #pragma unroll
     for (uint32_t q = 0; q < CREG; ++q)
         cols[q] = blockCols[(size_t)(myFirst + (uint32_t)WAVES * min(4u * q + g, myCount - 1u)) * 16u + r];
-    const uint32_t rowSlot = item.group * 16u;
-    uint32_t myRow = groupRows[rowSlot + r];
+    static_assert(H == 1 || WAVES == 1, "several panels per wave only in the one-wave form");
+    const uint32_t rowSlot = item.group * (16u * H);
+    uint32_t myRow[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) myRow[h] = groupRows[rowSlot + 16u * h + r];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (uint32_t q = 0; q < CREG; ++q) asm volatile("" : "+v"(cols[q]));
-    asm volatile("" : "+v"(myRow));
+#pragma unroll
+    for (int h = 0; h < H; ++h) asm volatile("" : "+v"(myRow[h]));
     // ring of SLOTS block images per wave: SLOTS-1 gathers stay in flight (a gather takes
     // ~1200 cycles under load, a block's MFMAs ~400: measured with in-kernel stamps)
     auto gather = [&](uint32_t u) {  // image u = (my block u / SPLIT, k range u % SPLIT) -> slot u % SLOTS
@@ -476,23 +482,31 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     //    in flight together.  The A loads are issued through inline assembly so that the compiler,
     //    which cannot count past an LDS-DMA, does not put a vmcnt(0) in front of their first use;
     //    the counted wait of the first block (all but the youngest KS operations) covers them.
-    f32x4 acc[MAXB];
+    f32x4 acc[MAXB][H];
     gather(0);
-    u32x4 a[KS];
-    {
-        const uint16_t* aRow = A16 + (size_t)myRow * K + g * 8u;
+    u32x4 a[H][KS];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const uint16_t* aRow = A16 + (size_t)myRow[h] * K + g * 8u;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[s]) : "v"(aRow + s * 32) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[h][s]) : "v"(aRow + s * 32) : "memory");
     }
-    TileRaw tile[MAXB];
+    TileRaw tile[MAXB][H];
 #pragma unroll
     for (uint32_t m = 0; m < (uint32_t)MAXB; ++m)
-        if (m < myCount) tile[m] = loadTile<TileT>(tiles, (size_t)(myFirst + (uint32_t)WAVES * m), lane);
-    uint32_t rowBase[4];
+        if (m < myCount) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        rowBase[i] = WINDOWED ? rowBaseTable[(size_t)itemId * 16u + 4u * g + i] : rowBaseTable[rowSlot + 4u * g + i];
+            for (int h = 0; h < H; ++h)
+                tile[m][h] = loadTile<TileT>(tiles, (size_t)(myFirst + (uint32_t)WAVES * m) * H + h, lane);
+        }
+    uint32_t rowBase[H][4];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rowBase[h][i] = WINDOWED ? rowBaseTable[(size_t)itemId * (16u * H) + 16u * h + 4u * g + i]
+                                     : rowBaseTable[rowSlot + 16u * h + 4u * g + i];
     const uint32_t units = myCount * SPLIT;
 #pragma unroll
     for (uint32_t u = 1; u + 1 < SLOTS; ++u)
@@ -500,10 +514,12 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
 #pragma unroll
     for (uint32_t m = 0; m < (uint32_t)MAXB; ++m) {
         if (m >= myCount) break;  // wave-uniform
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        f32x4 c[H];
 #pragma unroll
-        for (uint32_t h = 0; h < SPLIT; ++h) {
-            const uint32_t u = m * SPLIT + h;
+        for (int h = 0; h < H; ++h) c[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (uint32_t half = 0; half < SPLIT; ++half) {
+            const uint32_t u = m * SPLIT + half;
             // slot (u + SLOTS - 1) % SLOTS held image u-1, whose reads returned before its MFMAs
             if (u + SLOTS - 1 < units) gather(u + SLOTS - 1);
             const uint32_t younger = min(units - 1u - u, SLOTS - 1u);  // gathers issued after image u's
@@ -512,21 +528,28 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
             else waitInFlight(2);
             if (u == 0) {  // the A fragments have landed with the first image
 #pragma unroll
-                for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[s]));
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[h][s]));
             }
             const uint8_t* bCol = myLds + (u % SLOTS) * blkBytes + r * rowBytes;
 #pragma unroll
             for (int s = 0; s < (int)KSL; ++s) {
                 const u32x4 bv = *reinterpret_cast<const u32x4*>(bCol + (((4u * s + g) ^ (r & SW)) << 4));
-                c = mfma16<MODE>(a[h * KSL + s], bv, c);
+#pragma unroll
+                for (int h = 0; h < H; ++h) c[h] = mfma16<MODE>(a[h][half * KSL + s], bv, c[h]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        acc[m] = c;
+#pragma unroll
+        for (int h = 0; h < H; ++h) acc[m][h] = c[h];
     }
 #pragma unroll
     for (uint32_t m = 0; m < (uint32_t)MAXB; ++m)
-        if (m < myCount) scatterTile<TileT>(acc[m], tile[m], rowBase, P);
+        if (m < myCount) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) scatterTile<TileT>(acc[m][h], tile[m][h], rowBase[h], P);
+        }
 }
 
 // ---------------------------------------------------------------------------

@@ -141,6 +141,7 @@ def test_large_k_sparse_without_lds(engine, oracle):
     {"BSMR_DENSE_BLOCKS_PER_WG": "1"}, {"BSMR_DENSE_BLOCKS_PER_WG": "5", "BSMR_DENSE_GROUP": "2"},
     {"BSMR_STREAM_WAVES": "4"}, {"BSMR_STREAM_WAVES": "4", "BSMR_DENSE_BLOCKS_PER_WG": "13"},
     {"BSMR_DENSE_BLOCKS_PER_WG": "8"}, {"BSMR_DENSE_BLOCKS_PER_WG": "32"},
+    {"BSMR_DENSE_GROUP": "2", "BSMR_DENSE_BLOCKS_PER_WG": "8"}, {"BSMR_DENSE_GROUP": "2", "BSMR_DENSE_BLOCKS_PER_WG": "3"},
     {"BSMR_FREE_RESIDUE": "1"}, {"BSMR_FREE_RESIDUE": "1", "BSMR_SPARSE_LOWP": "0"}, {"BSMR_FREE_RESIDUE": "0"},
 ])
 @pytest.mark.parametrize("K", [32, 128, 512])
