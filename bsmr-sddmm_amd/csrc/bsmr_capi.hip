@@ -719,7 +719,9 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         if (st == BSMR_OK) st = upload(p->sparseItems, pk.sparseItems, p->indexBytes);
 
         // second dense format (4 panels per group) for gather-bound calls
-        if (st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8) {
+        // (only when it could ever be chosen: chooseFormat wants at least half the ungrouped columns gone)
+        if (st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8 &&
+            pk.unionColumns >= 2 * bsmr::countUnionColumns(d, 4)) {
             bsmr::PackedPlan pk4;
             opt.group = 4;
             opt.blocksPerItem = envInt("BSMR_DENSE_BLOCKS_PER_WG", 32);

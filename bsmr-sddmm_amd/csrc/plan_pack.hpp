@@ -31,13 +31,54 @@
 
 #include <algorithm>
 #include <cstdint>
-#include <unordered_map>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "bsmr_hip.h"
 #include "sddmm_kernels.hpp"
 
 namespace bsmr {
+
+// Host threads for plan packing: hardware threads capped by the control group's CPU quota and
+// BSMR_HOST_THREADS (same rule as util::hostThreads of the host library).
+inline unsigned packThreads() {
+    static unsigned cached = 0;
+    if (cached) return cached;
+    long limit = (long)std::max(1u, std::thread::hardware_concurrency());
+    if (const char* env = std::getenv("BSMR_HOST_THREADS")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v > 0) limit = std::min(limit, v);
+    } else if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        long long period = 0;
+        if (std::fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm' && period > 0) {
+            const long long quota = std::strtoll(q, nullptr, 10);
+            if (quota > 0) limit = std::min<long>(limit, (long)((quota + period - 1) / period));
+        }
+        std::fclose(f);
+    }
+    cached = (unsigned)std::max(1L, std::min(limit, 32L));
+    return cached;
+}
+
+// fn(begin, end, worker) over [0, n) in contiguous chunks, one per worker
+template <typename F>
+inline void parallelChunks(size_t n, size_t minPerWorker, F fn) {
+    const size_t workers = std::max<size_t>(1, std::min<size_t>(packThreads(), n / std::max<size_t>(1, minPerWorker)));
+    if (workers <= 1) {
+        fn((size_t)0, n, (size_t)0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (n + workers - 1) / workers;
+    for (size_t w = 0; w < workers; ++w) {
+        const size_t b = std::min(n, w * per), e = std::min(n, b + per);
+        if (b < e) pool.emplace_back([=, &fn]() { fn(b, e, w); });
+    }
+    for (std::thread& t : pool) t.join();
+}
 
 struct PackOptions {
     int group = 1;            // panels per group: 1, 2 or 4
@@ -84,12 +125,22 @@ struct ColumnUse {
     int32_t slot[kMaxGroup];     // position in each panel's dense list, -1 = not dense there
 };
 
+// Per-column scratch of unionColumns: position of a column in the current group's list (valid where the
+// stamp equals the group's).  Sized to N + 1 once per packPlan call.
+struct ColumnIndex {
+    std::vector<uint32_t> stamp, position;
+    uint32_t epoch = 0;
+    explicit ColumnIndex(size_t columns) : stamp(columns, 0), position(columns, 0) {}
+};
+
 // Distinct dense columns of the panels [p0, p0+h) with their per-panel slots.
 inline void unionColumns(const bsmr_rphm_desc* d, uint32_t p0, uint32_t h, uint32_t P,
-                         std::vector<ColumnUse>& out, std::unordered_map<uint32_t, uint32_t>& index,
-                         bool byColumnId) {
+                         std::vector<ColumnUse>& out, ColumnIndex& index, bool byColumnId) {
     out.clear();
-    index.clear();
+    if (++index.epoch == 0) {
+        std::fill(index.stamp.begin(), index.stamp.end(), 0u);
+        index.epoch = 1;
+    }
     for (uint32_t k = 0; k < h && p0 + k < P; ++k) {
         const uint32_t p = p0 + k;
         const uint64_t firstBlock = d->block_offsets[p];
@@ -100,14 +151,15 @@ inline void unionColumns(const bsmr_rphm_desc* d, uint32_t p0, uint32_t h, uint3
             const uint32_t* tile = d->block_values + (firstBlock + t / 16) * 256;
             uint32_t cnt = 0;
             for (uint32_t r = 0; r < 16; ++r) cnt += tile[r * 16 + t % 16] != 0xFFFFFFFFu;
-            auto it = index.find(col);
-            if (it == index.end()) {
-                it = index.emplace(col, (uint32_t)out.size()).first;
+            if (index.stamp[col] != index.epoch) {
+                index.stamp[col] = index.epoch;
+                index.position[col] = (uint32_t)out.size();
                 ColumnUse u{col, 0, {-1, -1, -1, -1}};
                 out.push_back(u);
             }
-            out[it->second].count += cnt;
-            out[it->second].slot[k] = (int32_t)t;
+            ColumnUse& use = out[index.position[col]];
+            use.count += cnt;
+            use.slot[k] = (int32_t)t;
         }
     }
     if (!byColumnId) {
@@ -148,6 +200,23 @@ inline void unionColumns(const bsmr_rphm_desc* d, uint32_t p0, uint32_t h, uint3
 
 }  // namespace detail
 
+// Distinct dense columns summed over groups of `h` panels, without building anything: what a grouped
+// format would gather.
+inline uint64_t countUnionColumns(const bsmr_rphm_desc* d, uint32_t h) {
+    const uint32_t P = d->num_row_panels;
+    std::vector<uint32_t> stamp((size_t)d->N + 1, 0);
+    uint64_t total = 0;
+    for (uint32_t p0 = 0, group = 1; p0 < P; p0 += h, ++group)
+        for (uint32_t p = p0; p < std::min(P, p0 + h); ++p)
+            for (uint64_t i = (uint64_t)d->block_offsets[p] * 16; i < (uint64_t)d->block_offsets[p + 1] * 16; ++i) {
+                const uint32_t col = d->dense_cols[i];
+                if (col >= d->N || stamp[col] == group) continue;
+                stamp[col] = group;
+                ++total;
+            }
+    return total;
+}
+
 // Returns a bsmr_hip.h status.
 inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan& out) {
     const uint32_t P = d->num_row_panels;
@@ -172,24 +241,37 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
     std::vector<uint32_t> panelRowBase((size_t)P * 16, 0);
     uint32_t maxOffset = 0;
     out.numDenseEntries = 0;
-    for (uint32_t p = 0; p < P; ++p) {
-        uint32_t lo[16], hi[16];
-        for (int r = 0; r < 16; ++r) { lo[r] = kNone; hi[r] = 0; }
-        for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b) {
-            const uint32_t* tile = d->block_values + b * 256;
-            for (uint32_t i = 0; i < 256; ++i) {
-                const uint32_t v = tile[i];
-                if (v == kNone) continue;
-                if (v >= d->nnz) return BSMR_ERR_BAD_PLAN;
-                ++out.numDenseEntries;
-                lo[i >> 4] = std::min(lo[i >> 4], v);
-                hi[i >> 4] = std::max(hi[i >> 4], v);
+    {
+        const unsigned workers = packThreads();
+        std::vector<uint64_t> entries(workers, 0);
+        std::vector<uint32_t> widest(workers, 0);
+        std::vector<uint8_t> bad(workers, 0);
+        parallelChunks(P, 64, [&](size_t q0, size_t q1, size_t w) {
+            for (size_t p = q0; p < q1; ++p) {
+                uint32_t lo[16], hi[16];
+                for (int r = 0; r < 16; ++r) { lo[r] = kNone; hi[r] = 0; }
+                for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b) {
+                    const uint32_t* tile = d->block_values + b * 256;
+                    for (uint32_t i = 0; i < 256; ++i) {
+                        const uint32_t v = tile[i];
+                        if (v == kNone) continue;
+                        if (v >= d->nnz) { bad[w] = 1; continue; }
+                        ++entries[w];
+                        lo[i >> 4] = std::min(lo[i >> 4], v);
+                        hi[i >> 4] = std::max(hi[i >> 4], v);
+                    }
+                }
+                for (int r = 0; r < 16; ++r) {
+                    if (lo[r] == kNone) continue;
+                    panelRowBase[p * 16 + r] = lo[r];
+                    widest[w] = std::max(widest[w], hi[r] - lo[r]);
+                }
             }
-        }
-        for (int r = 0; r < 16; ++r) {
-            if (lo[r] == kNone) continue;
-            panelRowBase[(size_t)p * 16 + r] = lo[r];
-            maxOffset = std::max(maxOffset, hi[r] - lo[r]);
+        });
+        for (unsigned w = 0; w < workers; ++w) {
+            if (bad[w]) return BSMR_ERR_BAD_PLAN;
+            out.numDenseEntries += entries[w];
+            maxOffset = std::max(maxOffset, widest[w]);
         }
     }
     for (uint64_t i = 0; i < numRefBlocks * 16; ++i)
@@ -207,43 +289,51 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
     std::copy(panelRowBase.begin(), panelRowBase.end(), groupRowBase.begin());
 
     // ---- dense blocks: columns, masks and absolute destinations -----------------
-    std::vector<detail::ColumnUse> cols;
-    std::unordered_map<uint32_t, uint32_t> index;
+    // phase 1 (parallel over groups): each group's column list
+    std::vector<std::vector<detail::ColumnUse>> groupCols(G);
+    parallelChunks(G, 8, [&](size_t g0, size_t g1, size_t) {
+        detail::ColumnIndex index((size_t)d->N + 1);
+        for (size_t gi = g0; gi < g1; ++gi)
+            detail::unionColumns(d, (uint32_t)gi * H, H, P, groupCols[gi], index, opt.columnOrder);
+    });
     std::vector<uint32_t> absTiles;               // [NB*H*256] CSR index or kNone, lane-major
     std::vector<uint32_t> groupFirstBlock(G + 1, 0);
-    out.blockCols.clear();
-    out.blockMask.clear();
     out.unionColumns = 0;
     for (uint32_t gi = 0; gi < G; ++gi) {
-        const uint32_t p0 = gi * H;
-        detail::unionColumns(d, p0, H, P, cols, index, opt.columnOrder);
-        out.unionColumns += cols.size();
-        const uint32_t blocks = (uint32_t)((cols.size() + 15) / 16);
-        const uint64_t firstBlock = out.blockMask.size();
-        groupFirstBlock[gi] = (uint32_t)firstBlock;
-        out.blockCols.resize((firstBlock + blocks) * 16, 0);
-        out.blockMask.resize(firstBlock + blocks, 0);
-        absTiles.resize((firstBlock + blocks) * H * 256, kNone);
-        for (size_t u = 0; u < cols.size(); ++u) {
-            const uint64_t b = firstBlock + u / 16;
-            const uint32_t cc = (uint32_t)(u % 16);
-            out.blockCols[b * 16 + cc] = cols[u].col;
-            for (uint32_t k = 0; k < H && p0 + k < P; ++k) {
-                const int32_t t = cols[u].slot[k];
-                if (t < 0) continue;
-                const uint32_t p = p0 + k;
-                const uint32_t* tile = d->block_values + ((uint64_t)d->block_offsets[p] + t / 16) * 256;
-                for (uint32_t r = 0; r < 16; ++r) {
-                    const uint32_t v = tile[r * 16 + t % 16];
-                    if (v == kNone) continue;
-                    const uint32_t lane = (r >> 2) * 16 + cc, i = r & 3u;
-                    absTiles[(b * H + k) * 256 + lane * 4 + i] = v;
-                    out.blockMask[b] |= (uint8_t)(1u << k);
+        out.unionColumns += groupCols[gi].size();
+        groupFirstBlock[gi + 1] = groupFirstBlock[gi] + (uint32_t)((groupCols[gi].size() + 15) / 16);
+    }
+    const size_t totalBlocks = groupFirstBlock[G];
+    out.blockCols.assign(totalBlocks * 16, 0);
+    out.blockMask.assign(totalBlocks, 0);
+    absTiles.assign(totalBlocks * H * 256, kNone);
+    // phase 2 (parallel over groups): columns, masks and absolute destinations at their final places
+    parallelChunks(G, 8, [&](size_t g0, size_t g1, size_t) {
+        for (size_t gi = g0; gi < g1; ++gi) {
+            const std::vector<detail::ColumnUse>& cols = groupCols[gi];
+            const uint32_t p0 = (uint32_t)gi * H;
+            const uint64_t firstBlock = groupFirstBlock[gi];
+            for (size_t u = 0; u < cols.size(); ++u) {
+                const uint64_t b = firstBlock + u / 16;
+                const uint32_t cc = (uint32_t)(u % 16);
+                out.blockCols[b * 16 + cc] = cols[u].col;
+                for (uint32_t k = 0; k < H && p0 + k < P; ++k) {
+                    const int32_t t = cols[u].slot[k];
+                    if (t < 0) continue;
+                    const uint32_t p = p0 + k;
+                    const uint32_t* tile = d->block_values + ((uint64_t)d->block_offsets[p] + t / 16) * 256;
+                    for (uint32_t r = 0; r < 16; ++r) {
+                        const uint32_t v = tile[r * 16 + t % 16];
+                        if (v == kNone) continue;
+                        const uint32_t lane = (r >> 2) * 16 + cc, i = r & 3u;
+                        absTiles[(b * H + k) * 256 + lane * 4 + i] = v;
+                        out.blockMask[b] |= (uint8_t)(1u << k);
+                    }
                 }
             }
         }
-    }
-    groupFirstBlock[G] = (uint32_t)out.blockMask.size();
+    });
+    { std::vector<std::vector<detail::ColumnUse>>().swap(groupCols); }
     out.numBlocks = out.blockMask.size();
     out.numTiles = 0;
     for (const uint8_t m : out.blockMask) out.numTiles += __builtin_popcount(m);
@@ -308,23 +398,25 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
         out.tiles8.assign(out.numBlocks * H * 256, 0xFF);
         out.tiles16.clear();
         out.tiles32.clear();
-        for (size_t it = 0; it < numItems; ++it) {
-            const DenseItem& item = out.denseItems[it];
-            for (uint32_t r = 0; r < R; ++r)
-                if (itemLo[it * R + r] != kNone) out.rowBase[it * R + r] = itemLo[it * R + r];
-            for (uint32_t b = item.first; b < item.first + item.count; ++b)
-                for (uint32_t k = 0; k < H; ++k)
-                    for (uint32_t e = 0; e < 256; ++e) {
-                        const size_t at = ((size_t)b * H + k) * 256 + e;
-                        const uint32_t v = absTiles[at];
-                        if (v == kNone) continue;
-                        const uint32_t row = rowOfElement(k, e);
-                        const uint32_t off = v - itemLo[it * R + row];
-                        out.tiles8[at] = (uint8_t)off;
-                        out.winMask[(it * R + row) * (kWindow / 32) + off / 32] |= 1u << (off % 32);
-                        out.winLen[it * R + row] = std::max<uint16_t>(out.winLen[it * R + row], (uint16_t)(off + 1));
-                    }
-        }
+        parallelChunks(numItems, 64, [&](size_t i0, size_t i1, size_t) {
+            for (size_t it = i0; it < i1; ++it) {
+                const DenseItem& item = out.denseItems[it];
+                for (uint32_t r = 0; r < R; ++r)
+                    if (itemLo[it * R + r] != kNone) out.rowBase[it * R + r] = itemLo[it * R + r];
+                for (uint32_t b = item.first; b < item.first + item.count; ++b)
+                    for (uint32_t k = 0; k < H; ++k)
+                        for (uint32_t e = 0; e < 256; ++e) {
+                            const size_t at = ((size_t)b * H + k) * 256 + e;
+                            const uint32_t v = absTiles[at];
+                            if (v == kNone) continue;
+                            const uint32_t row = rowOfElement(k, e);
+                            const uint32_t off = v - itemLo[it * R + row];
+                            out.tiles8[at] = (uint8_t)off;
+                            out.winMask[(it * R + row) * (kWindow / 32) + off / 32] |= 1u << (off % 32);
+                            out.winLen[it * R + row] = std::max<uint16_t>(out.winLen[it * R + row], (uint16_t)(off + 1));
+                        }
+            }
+        });
     } else {
         out.denseItems.clear();
         for (uint32_t gi = 0; gi < G; ++gi)
@@ -388,19 +480,17 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
             d->sparse_relative_rows[i] >= 16)
             return BSMR_ERR_BAD_PLAN;
     {
-        std::vector<uint32_t> perm;
+        std::vector<uint64_t> keys;  // (column, position in the panel): one plain sort = stable by column
         for (uint32_t p = 0; p < P; ++p) {
             const uint32_t s0 = d->sparse_value_offsets[p], s1 = d->sparse_value_offsets[p + 1];
-            perm.resize(s1 - s0);
-            for (uint32_t i = 0; i < s1 - s0; ++i) perm[i] = s0 + i;
-            if (opt.columnOrder)
-                std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) {
-                    return d->sparse_col_indices[a] < d->sparse_col_indices[b];
-                });
+            keys.resize(s1 - s0);
+            for (uint32_t i = 0; i < s1 - s0; ++i) keys[i] = ((uint64_t)d->sparse_col_indices[s0 + i] << 32) | i;
+            if (opt.columnOrder) std::sort(keys.begin(), keys.end());
             for (uint32_t i = 0; i < s1 - s0; ++i) {
-                out.entryCol[s0 + i] = d->sparse_col_indices[perm[i]];
-                out.entryDst[s0 + i] = d->sparse_values[perm[i]];
-                out.entryRow[s0 + i] = (uint8_t)d->sparse_relative_rows[perm[i]];
+                const uint32_t from = s0 + (uint32_t)(keys[i] & 0xFFFFFFFFu);
+                out.entryCol[s0 + i] = d->sparse_col_indices[from];
+                out.entryDst[s0 + i] = d->sparse_values[from];
+                out.entryRow[s0 + i] = (uint8_t)d->sparse_relative_rows[from];
             }
         }
     }
