@@ -47,11 +47,11 @@ def local_slice(rows, cols, ro, ci, r0, r1):
     return r1 - r0, cols, lro, ci[e0:e1].copy(), e0, e1 - e0
 
 
-def gather_to_root(dist, rank, world, local_out, root_out, offsets, counts):
-    """One gather-v: peers send their compact outputs into root_out[offsets[r]:+counts[r]].
-    On the root the local result already lives in its own slot of root_out."""
+def start_gather(dist, rank, world, local_out, root_out, offsets, counts):
+    """Issues one gather-v and returns its requests: peers send their compact outputs into
+    root_out[offsets[r]:+counts[r]].  On the root the local result already lives in its own slot."""
     if world == 1:
-        return
+        return []
     ops = []
     if rank == 0:
         for r in range(1, world):
@@ -59,9 +59,45 @@ def gather_to_root(dist, rank, world, local_out, root_out, offsets, counts):
                 ops.append(dist.P2POp(dist.irecv, root_out[offsets[r]:offsets[r] + counts[r]], r))
     elif counts[rank]:
         ops.append(dist.P2POp(dist.isend, local_out, 0))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
+    return list(dist.batch_isend_irecv(ops)) if ops else []
+
+
+def gather_to_root(dist, rank, world, local_out, root_out, offsets, counts):
+    """One gather-v, completed before returning (stream-ordered on GPU backends)."""
+    for req in start_gather(dist, rank, world, local_out, root_out, offsets, counts):
+        req.wait()
+
+
+class PipelinedSteps:
+    """SDDMM + gather, step after step, with the gather of step i in flight while step i+1 computes.
+
+    Two output buffers alternate (on the root: two full P vectors, the local result being a view into the
+    current one), so a step's gathered P stays intact until the step after next starts.  Every step still
+    ends with its own gather; only the wait for it is issued one step later.  `compute(buf)` fills the local
+    output `buf`."""
+
+    def __init__(self, dist, rank, world, offsets, counts, local_outs, root_outs):
+        self.dist, self.rank, self.world = dist, rank, world
+        self.offsets, self.counts = offsets, counts
+        self.local_outs, self.root_outs = local_outs, root_outs
+        self.pending = []
+        self.index = 0
+
+    def step(self, compute):
+        b = self.index & 1
+        self.index += 1
+        compute(self.local_outs[b])
+        reqs = start_gather(self.dist, self.rank, self.world, self.local_outs[b], self.root_outs[b], self.offsets,
+                            self.counts)
+        for req in self.pending:      # the previous step's gather, overlapped with this step's compute
             req.wait()
+        self.pending = reqs
+        return b
+
+    def drain(self):
+        for req in self.pending:
+            req.wait()
+        self.pending = []
 
 
 def sharded_sddmm(dist, rank, world, ro, counts_offsets, compute, local_out, root_out):
@@ -104,25 +140,35 @@ def run_sharded(eng, torch, dist, dev, rank, world, make_pattern, K, alpha, delt
     plan_s = time.perf_counter() - t0
     A = torch.from_numpy(eng.make_data(lrows * K, 5489 + 17 * rank)).to(dev)
     B = torch.from_numpy(eng.make_data(cols * K, 5490)).to(dev)   # replicated
-    root_out = torch.zeros(total_nnz if rank == 0 else 1, dtype=torch.float32, device=dev)
-    local_out = root_out[:lnnz] if rank == 0 else torch.zeros(max(lnnz, 1), dtype=torch.float32, device=dev)[:lnnz]
+    root_outs = [torch.zeros(total_nnz if rank == 0 else 1, dtype=torch.float32, device=dev) for _ in range(2)]
+    local_outs = [root_outs[b][:lnnz] if rank == 0
+                  else torch.zeros(max(lnnz, 1), dtype=torch.float32, device=dev)[:lnnz] for b in range(2)]
+    local_out = local_outs[0]
     sh = torch.cuda.current_stream(dev).cuda_stream
     eng.hip().bsmr_plan_reserve(pipe.plan, K)
 
-    def compute():
-        eng.sddmm(pipe.plan, K, A.data_ptr(), B.data_ptr(), local_out.data_ptr(), mode, sh)
+    def compute(buf):
+        eng.sddmm(pipe.plan, K, A.data_ptr(), B.data_ptr(), buf.data_ptr(), mode, sh)
+
+    # the gather of step i overlaps the compute of step i+1 (BSMR_SHARD_PIPELINE=0: strictly one after the other)
+    import os
+    pipelined = os.environ.get("BSMR_SHARD_PIPELINE", "1") != "0"
+    runner = PipelinedSteps(dist, rank, world, offsets, counts, local_outs, root_outs)
 
     def step():
-        compute()
-        gather_to_root(dist, rank, world, local_out, root_out, offsets, counts)
+        runner.step(compute)
+        if not pipelined:
+            runner.drain()
 
     for _ in range(warmup):
         step()
+    runner.drain()
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    runner.drain()
     torch.cuda.synchronize()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
@@ -139,7 +185,8 @@ def run_sharded(eng, torch, dist, dev, rank, world, make_pattern, K, alpha, delt
         "data": "synthetic",
         "config": {"workload": f"{world} row shards of {lrows} rows x {cols} cols, total {total_rows} rows, "
                                f"nnz {total_nnz}, K={K}, alpha={alpha}, delta={delta}",
-                   "parallelism": f"row-range shards x{world}, B replicated, one RCCL gather-v to rank 0 per step"},
+                   "parallelism": f"row-range shards x{world}, B replicated, one RCCL gather-v to rank 0 per step"
+                                  + (" (the gather of step i overlaps the compute of step i+1)" if pipelined else "")},
         "compute_only_ms_max": round(float(ct.item()), 5),
         "plan_build_s": round(plan_s, 3),
         # this rank's shard, for the caller's roofline (used on rank 0)

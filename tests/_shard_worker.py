@@ -73,6 +73,33 @@ def main():
             want = oracle.sddmm_cpu(rr, rc, K, rro, rci, eng.make_data(rr * K, 300 + r), B)
             seg = got[offsets[r]:offsets[r] + counts[r]]
             assert np.array_equal(seg.view(np.uint32), want.view(np.uint32)), f"weak: shard {r} differs"
+    # ---- pipelined steps: the gather of step i is waited for after step i+1 has computed; each step's
+    #      gathered P (step-dependent operands) must be intact when its buffer comes up again ----
+    root_outs = [torch.zeros(sum(counts) if rank == 0 else 1, dtype=torch.float32) for _ in range(2)]
+    local_outs = [root_outs[b][:counts[0]] if rank == 0 else torch.zeros(counts[rank], dtype=torch.float32)
+                  for b in range(2)]
+    runner = shard.PipelinedSteps(dist, rank, world, offsets, counts, local_outs, root_outs)
+    base = oracle.sddmm_cpu(prow, pcol, K, pro, pci, Ar, B)
+    seen = {}
+    for stepno in range(5):
+        scale = np.float32(stepno + 1)
+
+        def compute_step(buf, scale=scale):
+            buf.copy_(torch.from_numpy(base * scale))
+
+        b = runner.step(compute_step)
+        # the buffer of the previous step is complete now (its gather was waited for inside step())
+        if stepno >= 1 and rank == 0:
+            seen[stepno - 1] = root_outs[1 - b].numpy().copy()
+    runner.drain()
+    if rank == 0:
+        seen[4] = root_outs[0].numpy().copy()          # step 4 used buffer 0
+        for stepno, got in seen.items():
+            for r in range(world):
+                rr, rc, rro, rci = synth.random_pattern(40, cols, 600 + 50 * r, seed=100 + r)
+                want = oracle.sddmm_cpu(rr, rc, K, rro, rci, eng.make_data(rr * K, 300 + r), B) * np.float32(stepno + 1)
+                seg = got[offsets[r]:offsets[r] + counts[r]]
+                assert np.array_equal(seg.view(np.uint32), want.view(np.uint32)), f"pipelined step {stepno}, shard {r}"
         print("SHARD_OK", world)
     dist.barrier()
     dist.destroy_process_group()
