@@ -1009,11 +1009,13 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
     try {
         const size_t numBins = (size_t)std::ceil((float)cols / (float)bin_width);
         const uint32_t T = clusterThreads(numBins);
-        const size_t tableBytes = (size_t)rows * numBins * sizeof(uint32_t);
+        const size_t tableBytes = (size_t)rows * numBins * sizeof(bsmr::ClusterCount);
         size_t freeBytes = 0, totalBytes = 0;
         BSMR_HIP(hipMemGetInfo(&freeBytes, &totalBytes));
         // the rows x bins table has to fit beside the operands; the histogram of one row has to fit in LDS
-        if (tableBytes > freeBytes / 2 || numBins * sizeof(uint32_t) > 160u * 1024u - 64u) return BSMR_ERR_OOM;
+        // (a bin wider than 65535 columns would not fit the table's 16-bit entries)
+        if (tableBytes > freeBytes / 2 || numBins * sizeof(uint32_t) > 160u * 1024u - 64u || bin_width > 65535u)
+            return BSMR_ERR_OOM;
 
         hipEvent_t ev0, ev1;
         BSMR_HIP(hipEventCreate(&ev0));
@@ -1027,7 +1029,8 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
 
         DeviceBuffers dev;
         const uint32_t live = liveWarpMask(T);
-        uint32_t *dRowOffsets, *dCols, *dTable, *dDisp, *dSquares, *dOrder, *dCluster;
+        uint32_t *dRowOffsets, *dCols, *dDisp, *dSquares, *dOrder, *dCluster;
+        bsmr::ClusterCount* dTable;
         bsmr::ClusterState* dState;
         if (!dev.alloc(&dRowOffsets, (size_t)rows + 1, "hipMalloc(rowOffsets)") ||
             !dev.alloc(&dCols, nnz, "hipMalloc(colIndices)") || !dev.alloc(&dTable, (size_t)rows * numBins, "hipMalloc(table)") ||
@@ -1087,10 +1090,9 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
             state.slot[0].rep = 0;
             BSMR_HIP(hipMemcpyAsync(dOrder, order.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
             BSMR_HIP(hipMemcpyAsync(dCluster, cluster.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
-            BSMR_HIP(hipMemcpyAsync(dReps, dTable + (size_t)order[firstNonEmpty] * numBins, numBins * 4,
-                                    hipMemcpyDeviceToDevice, s));
             BSMR_HIP(hipMemcpyAsync(dState, &state, sizeof(state), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(bsmr::clusterInitSquares, dim3(1), dim3(T), 0, s, dReps, (uint32_t)numBins, live, dState);
+            hipLaunchKernelGGL(bsmr::clusterInitRepresentative, dim3(1), dim3(T), 0, s,
+                               dTable + (size_t)order[firstNonEmpty] * numBins, dReps, (uint32_t)numBins, live, dState);
             // every pass is a no-op once `done` is set, so passes are enqueued in batches and the
             // flag is read between batches; a pass that does work advances at least one cursor
             const uint64_t passLimit = 64ull * rows + 4096;

@@ -32,6 +32,9 @@
 namespace bsmr {
 
 constexpr uint32_t kNoCluster = 0xFFFFFFFFu;
+// One histogram entry of the rows x bins table: a row has at most binWidth <= 65535 entries in a bin, so 16
+// bits do (half the bytes of the reference's UIN table; the representatives, which add rows up, stay 32-bit).
+typedef uint16_t ClusterCount;
 constexpr uint32_t kClusterMinChunk = 32;
 
 constexpr uint32_t kClusterMaxActive = 16;
@@ -69,13 +72,13 @@ __device__ __forceinline__ bool binCounts(uint32_t b, uint32_t T, uint32_t liveW
 // (src/rowReordering.cu:49-93) and the row's sum of squares as the clustering block would see it
 __global__ void clusterHistogram(const uint32_t* __restrict__ rowOffsets, const uint32_t* __restrict__ colIndices,
                                  uint32_t numBins, uint32_t binWidth, uint32_t T, uint32_t liveWarps,
-                                 uint32_t* __restrict__ table, uint32_t* __restrict__ dispersion,
+                                 ClusterCount* __restrict__ table, uint32_t* __restrict__ dispersion,
                                  uint32_t* __restrict__ rowSquares) {
     extern __shared__ uint32_t hist[];
     __shared__ uint32_t partial[3];
     const uint32_t row = blockIdx.x;
     const uint32_t b = rowOffsets[row], e = rowOffsets[row + 1];
-    uint32_t* out = table + (size_t)row * numBins;
+    ClusterCount* out = table + (size_t)row * numBins;
     if (b == e) {
         if (threadIdx.x == 0) {
             dispersion[row] = 0;
@@ -91,7 +94,7 @@ __global__ void clusterHistogram(const uint32_t* __restrict__ rowOffsets, const 
     uint32_t touched = 0, slack = 0, squares = 0;
     for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
         const uint32_t v = hist[i];
-        out[i] = v;
+        out[i] = (ClusterCount)v;
         if (v) {
             ++touched;
             slack += binWidth - v;
@@ -136,7 +139,7 @@ __device__ __forceinline__ void blockSumAsReference(float& a, float& b, float* s
 // src/rowReordering.cu:235-293.  The two sums of squares are integers: their masked values are
 // kept per row (clusterHistogram) and per representative (ClusterState::sqRep).
 __device__ __forceinline__ float similarityAsReference(const uint32_t* __restrict__ rep, uint32_t sqRep,
-                                                       const uint32_t* __restrict__ cmp, uint32_t sqCmp,
+                                                       const ClusterCount* __restrict__ cmp, uint32_t sqCmp,
                                                        uint32_t numBins, float* shmA, float* shmB) {
     if (sqRep == 0 && sqCmp == 0) return 1.0f;
     if (sqRep == 0 || sqCmp == 0) return 0.0f;
@@ -156,7 +159,7 @@ __device__ __forceinline__ float similarityAsReference(const uint32_t* __restric
 // One speculative pass (see the header comment).  The positions to judge of all active clusters
 // form one list; workgroup g takes items g, g + G, ... (G = gridDim.x) and skips an item once an
 // earlier position of the same cluster has been accepted; block = T threads.
-__global__ void clusterPass(const uint32_t* __restrict__ table, const uint32_t* __restrict__ rowSquares,
+__global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__ rowSquares,
                             const uint32_t* __restrict__ order, uint32_t rows, uint32_t numBins, float alpha,
                             uint32_t maxChunk, uint32_t maxActive, uint32_t liveWarps, uint32_t* __restrict__ reps,
                             uint32_t* __restrict__ cluster, ClusterState* __restrict__ state) {
@@ -219,12 +222,12 @@ __global__ void clusterPass(const uint32_t* __restrict__ table, const uint32_t* 
 
     // rep = first (assign) or rep += first (merge); returns the new sum of squares over the bins
     // that count (UIN arithmetic: wraps).  Every thread only touches the bins it owns.
-    auto absorb = [&](uint32_t* __restrict__ rep, const uint32_t* __restrict__ first, bool merge) {
+    auto absorb = [&](uint32_t* __restrict__ rep, const ClusterCount* __restrict__ first, bool merge) {
         if (threadIdx.x == 0) shared[1] = 0;
         __syncthreads();
         uint32_t sq = 0;
         for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
-            const uint32_t v = merge ? rep[i] + first[i] : first[i];
+            const uint32_t v = merge ? rep[i] + (uint32_t)first[i] : (uint32_t)first[i];
             rep[i] = v;
             if (binCounts(i, blockDim.x, liveWarps)) sq += v * v;
         }
@@ -348,15 +351,18 @@ __global__ void clusterPass(const uint32_t* __restrict__ table, const uint32_t* 
     }
 }
 
-// sum of squares of the first representative (same definition as in clusterPass)
-__global__ void clusterInitSquares(const uint32_t* __restrict__ rep, uint32_t numBins, uint32_t liveWarps,
-                                   ClusterState* __restrict__ state) {
+// first representative = the seed row's histogram; its sum of squares as in clusterPass
+__global__ void clusterInitRepresentative(const ClusterCount* __restrict__ seedRow, uint32_t* __restrict__ rep,
+                                          uint32_t numBins, uint32_t liveWarps, ClusterState* __restrict__ state) {
     __shared__ uint32_t total;
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
     uint32_t sq = 0;
-    for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x)
-        if (binCounts(i, blockDim.x, liveWarps)) sq += rep[i] * rep[i];
+    for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
+        const uint32_t v = seedRow[i];
+        rep[i] = v;
+        if (binCounts(i, blockDim.x, liveWarps)) sq += v * v;
+    }
     atomicAdd(&total, sq);
     __syncthreads();
     if (threadIdx.x == 0) state->slot[0].sq = total;
