@@ -1029,7 +1029,8 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
 
         DeviceBuffers dev;
         const uint32_t live = liveWarpMask(T);
-        uint32_t *dRowOffsets, *dCols, *dDisp, *dSquares, *dOrder, *dCluster;
+        uint32_t *dRowOffsets, *dCols, *dDisp, *dSquares, *dOrder, *dCluster, *dEncOffsets = nullptr, *dEncBins = nullptr;
+        uint16_t* dEncCounts = nullptr;
         bsmr::ClusterCount* dTable;
         bsmr::ClusterState* dState;
         if (!dev.alloc(&dRowOffsets, (size_t)rows + 1, "hipMalloc(rowOffsets)") ||
@@ -1054,6 +1055,63 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
         std::vector<uint32_t> disp(rows);
         BSMR_HIP(hipMemcpyAsync(disp.data(), dDisp, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
         BSMR_HIP(hipStreamSynchronize(s));
+
+        // sparse (bin, count) list per row for the O(|row|) similarity decision (bins ascending), built when the
+        // passes first need it: two parallel sweeps over the rows (count, then fill), sorting only rows whose
+        // columns are not ascending
+        auto uploadSparseRows = [&]() -> int {
+            std::vector<uint32_t> encOffsets((size_t)rows + 1, 0), encBins;
+            std::vector<uint16_t> encCounts;
+            auto forRowBins = [&](uint32_t r, std::vector<uint32_t>& scratch, auto&& emit) {
+                const uint32_t b = row_offsets[r], e = row_offsets[r + 1];
+                bool ascending = true;
+                for (uint32_t i = b + 1; i < e && ascending; ++i) ascending = col_indices[i - 1] <= col_indices[i];
+                const uint32_t* cols = col_indices + b;
+                if (!ascending) {
+                    scratch.assign(col_indices + b, col_indices + e);
+                    std::sort(scratch.begin(), scratch.end());
+                    cols = scratch.data();
+                }
+                for (uint32_t i = 0; i < e - b;) {
+                    const uint32_t bin = cols[i] / bin_width;
+                    uint32_t j = i;
+                    while (j < e - b && cols[j] / bin_width == bin) ++j;
+                    emit(bin, j - i);
+                    i = j;
+                }
+            };
+            bsmr::parallelChunks(rows, 1024, [&](size_t r0, size_t r1, size_t) {
+                std::vector<uint32_t> scratch;
+                for (size_t r = r0; r < r1; ++r) {
+                    uint32_t runs = 0;
+                    forRowBins((uint32_t)r, scratch, [&](uint32_t, uint32_t) { ++runs; });
+                    encOffsets[r + 1] = runs;
+                }
+            });
+            for (uint32_t r = 0; r < rows; ++r) encOffsets[r + 1] += encOffsets[r];
+            encBins.resize(encOffsets[rows]);
+            encCounts.resize(encOffsets[rows]);
+            bsmr::parallelChunks(rows, 1024, [&](size_t r0, size_t r1, size_t) {
+                std::vector<uint32_t> scratch;
+                for (size_t r = r0; r < r1; ++r) {
+                    uint32_t at = encOffsets[r];
+                    forRowBins((uint32_t)r, scratch, [&](uint32_t bin, uint32_t count) {
+                        encBins[at] = bin;
+                        encCounts[at++] = (uint16_t)count;
+                    });
+                }
+            });
+            if (!dev.alloc(&dEncOffsets, (size_t)rows + 1, "hipMalloc(encOffsets)") ||
+                !dev.alloc(&dEncBins, encBins.size(), "hipMalloc(encBins)") ||
+                !dev.alloc(&dEncCounts, encCounts.size(), "hipMalloc(encCounts)"))
+                return BSMR_ERR_OOM;
+            BSMR_HIP(hipMemcpy(dEncOffsets, encOffsets.data(), ((size_t)rows + 1) * 4, hipMemcpyHostToDevice));
+            if (!encBins.empty()) {
+                BSMR_HIP(hipMemcpy(dEncBins, encBins.data(), encBins.size() * 4, hipMemcpyHostToDevice));
+                BSMR_HIP(hipMemcpy(dEncCounts, encCounts.data(), encCounts.size() * 2, hipMemcpyHostToDevice));
+            }
+            return BSMR_OK;
+        };
 
         // 2. ascending dispersion, ties in ascending row id (src/rowReordering.cu:1056-1062)
         std::vector<uint32_t> order(rows);
@@ -1097,18 +1155,34 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
             // flag is read between batches; a pass that does work advances at least one cursor
             const uint64_t passLimit = 64ull * rows + 4096;
             uint64_t enqueued = 0;
+            // which form of the pass the next batch uses: the one-wave-per-item form once the passes of the last
+            // batch judged more items than there are workgroups
+            bool many = false;
+            uint64_t lastWork = 0, lastPasses = 0;
             while (!state.done) {
                 if (enqueued > passLimit) {
                     g_lastHipError = "bsmr_cluster_rows: pass limit reached";
                     return BSMR_ERR_HIP;
                 }
-                for (int i = 0; i < 128; ++i)
-                    hipLaunchKernelGGL(bsmr::clusterPass, dim3(grid), dim3(T), 0, s, dTable, dSquares, dOrder, rows,
-                                       (uint32_t)numBins, alpha, maxChunk, active, live, dReps, dCluster, dState);
-                enqueued += 128;
+                for (int i = 0; i < 256; ++i) {
+                    if (many)
+                        hipLaunchKernelGGL(bsmr::clusterPass<true>, dim3(grid), dim3(T), 0, s, dTable, dSquares, dEncOffsets,
+                                           dEncBins, dEncCounts, dOrder, rows, (uint32_t)numBins, alpha, maxChunk, active, live,
+                                           dReps, dCluster, dState);
+                    else
+                        hipLaunchKernelGGL(bsmr::clusterPass<false>, dim3(grid), dim3(T), 0, s, dTable, dSquares, dEncOffsets,
+                                           dEncBins, dEncCounts, dOrder, rows, (uint32_t)numBins, alpha, maxChunk, active, live,
+                                           dReps, dCluster, dState);
+                }
+                enqueued += 256;
                 BSMR_HIP(hipGetLastError());
                 BSMR_HIP(hipMemcpyAsync(&state, dState, sizeof(state), hipMemcpyDeviceToHost, s));
                 BSMR_HIP(hipStreamSynchronize(s));
+                const uint64_t work = (uint64_t)state.judged + state.exact, passes = state.passes;
+                if (passes > lastPasses) many = (work - lastWork) > (uint64_t)grid * (passes - lastPasses);
+                if (many && !dEncOffsets && (st = uploadSparseRows()) != BSMR_OK) return st;
+                lastWork = work;
+                lastPasses = passes;
             }
             BSMR_HIP(hipMemcpyAsync(cluster.data(), dCluster, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
             BSMR_HIP(hipStreamSynchronize(s));
@@ -1138,6 +1212,7 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
             stats->elapsed_ms = ms;
             stats->passes = state.passes;
             stats->similarities = state.judged;
+            stats->exact_similarities = state.exact;
             stats->threads_per_pair = T;
             stats->table_bytes = tableBytes;
         }

@@ -22,6 +22,10 @@
 //     last workgroup to finish merges those rows, moves each cursor behind its hit - everything
 //     before it was judged with the right representative, everything after it is judged again -
 //     adapts the chunks, retires finished clusters and seeds the next one.
+//   * A similarity is only compared with alpha.  One thread forms the same quotient from the row's sparse
+//     (bin, count) list in double arithmetic - O(|row|) against O(bins) - which differs from the fp32
+//     block sum by a few 1e-6 at most; only pairs within 1e-4 of alpha are re-evaluated by the whole
+//     workgroup in the reference's exact order of operations (same rule as src/rowReordering.cpp).
 // All state lives in device memory, so the host only enqueues passes and polls a flag; a pass
 // that finds the work finished is a no-op.
 #pragma once
@@ -45,6 +49,7 @@ struct ClusterSlot {
     uint32_t chunk;     // positions judged by the next pass
     uint32_t id;        // cluster id (1-based; 0 = empty rows)
     uint32_t sq;        // representative's sum of squares over the bins that count (mod 2^32)
+    uint32_t total;     // representative's sum of counts over the bins that count
     uint32_t firstHit;  // smallest accepted position of the running pass
     uint32_t scan;      // positions in [seed + 1, scan) are assigned (search for the successor's seed)
     uint32_t rep;       // which representative buffer the cluster owns
@@ -58,7 +63,8 @@ struct ClusterState {
     uint32_t arrived;    // workgroups of the running pass that have finished
     uint32_t done;       // every row has a cluster
     uint32_t passes;     // statistics
-    uint32_t judged;     // statistics: similarities evaluated
+    uint32_t judged;     // statistics: similarities decided by the O(|row|) evaluation
+    uint32_t exact;      // statistics: similarities that needed the exact block-order evaluation
     ClusterSlot slot[kClusterMaxActive];
 };
 
@@ -156,20 +162,27 @@ __device__ __forceinline__ float similarityAsReference(const uint32_t* __restric
     return minSum / maxSum;
 }
 
-// One speculative pass (see the header comment).  The positions to judge of all active clusters
-// form one list; workgroup g takes items g, g + G, ... (G = gridDim.x) and skips an item once an
-// earlier position of the same cluster has been accepted; block = T threads.
+// One speculative pass (see the header comment).  The positions to judge of all active clusters form one
+// list; thread t of workgroup g takes items g*T + t, g*T + t + G*T, ... (G = gridDim.x, T = blockDim.x) and
+// skips an item once an earlier position of the same cluster has been accepted.
+template <bool MANY>
 __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__ rowSquares,
-                            const uint32_t* __restrict__ order, uint32_t rows, uint32_t numBins, float alpha,
-                            uint32_t maxChunk, uint32_t maxActive, uint32_t liveWarps, uint32_t* __restrict__ reps,
-                            uint32_t* __restrict__ cluster, ClusterState* __restrict__ state) {
+                            const uint32_t* __restrict__ encOffsets, const uint32_t* __restrict__ encBins,
+                            const uint16_t* __restrict__ encCounts, const uint32_t* __restrict__ order, uint32_t rows,
+                            uint32_t numBins, float alpha, uint32_t maxChunk, uint32_t maxActive, uint32_t liveWarps,
+                            uint32_t* __restrict__ reps, uint32_t* __restrict__ cluster,
+                            ClusterState* __restrict__ state) {
     __shared__ float shmA[32], shmB[32];
     __shared__ uint32_t shared[3];
     __shared__ uint32_t sCursor[kClusterMaxActive], sLen[kClusterMaxActive], sStart[kClusterMaxActive + 1];
-    __shared__ uint32_t sHit[kClusterMaxActive];
+    __shared__ uint32_t sHit[kClusterMaxActive], sSumSq[kClusterMaxActive], sSumTotal[kClusterMaxActive];
     __shared__ ClusterSlot sSlot[kClusterMaxActive + 1];
+    // MANY only: items of this round within 1e-4 of alpha, (cluster << 28) | offset in its window
+    __shared__ uint32_t sNear[MANY ? 1024 : 1];
+    __shared__ uint32_t sNearCount;
     if (state->done) return;  // uniform over the grid: the state only changes at the end of a pass
     const uint32_t active = state->numActive;
+    const uint32_t T = blockDim.x;
     if (threadIdx.x < active) sSlot[threadIdx.x] = state->slot[threadIdx.x];  // one slot per lane: one round trip
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -185,34 +198,112 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
             total += len;
         }
         sStart[active] = total;
+        sNearCount = 0;
     }
     __syncthreads();
     const uint32_t total = sStart[active];
-    if (blockIdx.x >= total) return;  // nothing to judge, and nobody waits for this workgroup
-    const uint32_t participants = total < gridDim.x ? total : gridDim.x;
-    uint32_t judged = 0;
-    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
-        uint32_t j = 0;
-        while (item >= sStart[j + 1]) ++j;
-        const uint32_t pos = sCursor[j] + (item - sStart[j]);
-        if (item != blockIdx.x) {  // later rounds: skip what lies behind an accepted position
-            if (threadIdx.x == 0)
-                shared[2] = __hip_atomic_load(&state->slot[j].firstHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const uint32_t best = shared[2];
-            __syncthreads();
-            if (best < pos) continue;
+    // one item per wave and round; the wave's lanes share the row's (bin, count) list
+    const uint32_t wavesPerWG = (T + 63u) >> 6;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t lanes = T - 64u * wave < 64u ? T - 64u * wave : 64u;  // 32 in the last wave when T % 64 == 32
+    // Two forms of one pass, picked by the host from the previous batch's statistics.  MANY = false: few
+    // items per pass, latency counts - every item is evaluated exactly by a whole workgroup straight from the
+    // dense table (two dependent loads instead of four, a small kernel).  MANY = true: throughput counts -
+    // one wave per item decides from the sparse list, the workgroup only re-evaluates the near ones.
+    const uint32_t wgsWithWork = MANY ? (total + wavesPerWG - 1) / wavesPerWG : total;
+    if (blockIdx.x >= wgsWithWork) return;  // nothing to judge, and nobody waits for this workgroup
+    const uint32_t participants = wgsWithWork < gridDim.x ? wgsWithWork : gridDim.x;
+    uint32_t judged = 0, exact = 0;
+    if constexpr (!MANY) {
+        for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+            uint32_t j = 0;
+            while (item >= sStart[j + 1]) ++j;
+            const uint32_t pos = sCursor[j] + (item - sStart[j]);
+            if (item != blockIdx.x) {  // later rounds: skip what lies behind an accepted position
+                if (threadIdx.x == 0)
+                    shared[2] = __hip_atomic_load(&state->slot[j].firstHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const uint32_t best = shared[2];
+                __syncthreads();
+                if (best < pos) continue;
+            }
+            if (cluster[pos] != kNoCluster) continue;
+            const uint32_t row = order[pos];
+            const float sim = similarityAsReference(reps + (size_t)sSlot[j].rep * numBins, sSlot[j].sq,
+                                                    table + (size_t)row * numBins, rowSquares[row], numBins, shmA, shmB);
+            ++exact;
+            if (threadIdx.x == 0 && sim > alpha) atomicMin(&state->slot[j].firstHit, pos);
         }
-        if (cluster[pos] != kNoCluster) continue;
-        const uint32_t row = order[pos];
-        const float sim = similarityAsReference(reps + (size_t)sSlot[j].rep * numBins, sSlot[j].sq,
-                                                table + (size_t)row * numBins, rowSquares[row], numBins, shmA, shmB);
-        ++judged;
-        if (threadIdx.x == 0 && sim > alpha) atomicMin(&state->slot[j].firstHit, pos);
+    }
+    for (uint32_t base = blockIdx.x * wavesPerWG; MANY && base < total; base += gridDim.x * wavesPerWG) {  // uniform
+        // -- decided from the row's sparse histogram unless it is close to alpha --
+        const uint32_t item = base + wave;
+        if (item < total) {
+            uint32_t j = 0;
+            while (item >= sStart[j + 1]) ++j;
+            const uint32_t pos = sCursor[j] + (item - sStart[j]);
+            const uint32_t best = __hip_atomic_load(&state->slot[j].firstHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pos < best && cluster[pos] == kNoCluster) {  // (wave-uniform up to the race on firstHit, which only prunes)
+                const uint32_t row = order[pos];
+                const uint32_t sqRep = sSlot[j].sq, sqRow = rowSquares[row];
+                if (lane == 0) ++judged;
+                bool hit = false, near = false;
+                if (sqRep == 0 || sqRow == 0) {  // src/rowReordering.cu:263-268
+                    hit = (sqRep == 0 && sqRow == 0 ? 1.0f : 0.0f) > alpha;
+                } else {
+                    const uint32_t* rep = reps + (size_t)sSlot[j].rep * numBins;
+                    const double normRep = (double)sqrtf((float)sqRep), normRow = (double)sqrtf((float)sqRow);
+                    double minSum = 0.0, maxShared = 0.0, repInRow = 0.0;  // counts < 2^53: exact in double
+                    for (uint32_t i = encOffsets[row] + lane; i < encOffsets[row + 1]; i += lanes) {
+                        const uint32_t bin = encBins[i];
+                        if (!binCounts(bin, T, liveWarps)) continue;
+                        const uint32_t c = rep[bin];
+                        const double x = (double)c / normRep, y = (double)encCounts[i] / normRow;
+                        minSum += x < y ? x : y;
+                        maxShared += x < y ? y : x;
+                        repInRow += (double)c;
+                    }
+                    for (uint32_t w = lanes >> 1; w >= 1; w >>= 1) {
+                        minSum += __shfl_xor(minSum, w, 64);
+                        maxShared += __shfl_xor(maxShared, w, 64);
+                        repInRow += __shfl_xor(repInRow, w, 64);
+                    }
+                    const double approx = minSum / (maxShared + ((double)sSlot[j].total - repInRow) / normRep);
+                    const double margin = approx - (double)alpha;
+                    if (margin > 1e-4) hit = true;
+                    else if (margin >= -1e-4) near = true;
+                }
+                if (lane == 0) {
+                    if (hit) atomicMin(&state->slot[j].firstHit, pos);
+                    if (near) sNear[atomicAdd(&sNearCount, 1u)] = (j << 28) | (item - sStart[j]);
+                }
+            }
+        }
+        __syncthreads();
+        // -- the near ones again, by the whole workgroup, in the reference's order of operations --
+        const uint32_t nearCount = sNearCount;
+        for (uint32_t n = 0; n < nearCount; ++n) {
+            const uint32_t j = sNear[n] >> 28, pos = sCursor[j] + (sNear[n] & 0x0FFFFFFFu);
+            const uint32_t row = order[pos];
+            const float sim = similarityAsReference(reps + (size_t)sSlot[j].rep * numBins, sSlot[j].sq,
+                                                    table + (size_t)row * numBins, rowSquares[row], numBins, shmA, shmB);
+            if (threadIdx.x == 0 && sim > alpha) atomicMin(&state->slot[j].firstHit, pos);
+        }
+        exact += nearCount;
+        __syncthreads();
+        if (threadIdx.x == 0) sNearCount = 0;
+        __syncthreads();
     }
     // the last workgroup to arrive closes the pass
+    if constexpr (MANY) {  // lane 0 of every wave counted its items
+        if (threadIdx.x == 0) shared[2] = 0;
+        __syncthreads();
+        if (judged) atomicAdd(&shared[2], judged);
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        if (judged) atomicAdd(&state->judged, judged);
+        if (MANY && shared[2]) atomicAdd(&state->judged, shared[2]);
+        if (exact) atomicAdd(&state->exact, exact);
         __threadfence();
         shared[0] = atomicAdd(&state->arrived, 1u) == participants - 1 ? 1u : 0u;
     }
@@ -220,20 +311,33 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
     if (!shared[0]) return;
     __threadfence();
 
+    uint32_t sTotal = 0;
     // rep = first (assign) or rep += first (merge); returns the new sum of squares over the bins
     // that count (UIN arithmetic: wraps).  Every thread only touches the bins it owns.
+    // Also leaves the new sum of counts over those bins in shared[2].
     auto absorb = [&](uint32_t* __restrict__ rep, const ClusterCount* __restrict__ first, bool merge) {
-        if (threadIdx.x == 0) shared[1] = 0;
+        if (threadIdx.x == 0) shared[1] = shared[2] = 0;
         __syncthreads();
-        uint32_t sq = 0;
+        uint32_t sq = 0, tot = 0;
         for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
             const uint32_t v = merge ? rep[i] + (uint32_t)first[i] : (uint32_t)first[i];
             rep[i] = v;
-            if (binCounts(i, blockDim.x, liveWarps)) sq += v * v;
+            if (binCounts(i, blockDim.x, liveWarps)) {
+                sq += v * v;
+                tot += v;
+            }
         }
-        atomicAdd(&shared[1], sq);
+        for (uint32_t w = lanes >> 1; w >= 1; w >>= 1) {
+            sq += __shfl_xor(sq, w, 64);
+            tot += __shfl_xor(tot, w, 64);
+        }
+        if ((threadIdx.x & 63u) == 0) {
+            atomicAdd(&shared[1], sq);
+            atomicAdd(&shared[2], tot);
+        }
         __syncthreads();
         const uint32_t sum = shared[1];
+        sTotal = shared[2];
         __syncthreads();
         return sum;
     };
@@ -253,35 +357,57 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
         return found;
     };
 
-    // 1. hits, oldest cluster first (sSlot is this workgroup's working copy; all threads run the
-    //    same control flow, thread 0 does the scalar writes)
-    if (threadIdx.x < active)
+    // 1. hits: every accepted row is merged into its cluster's representative.  The clusters are
+    //    independent here, so all merges run in one sweep (per-cluster sums: a wave adds its lanes up
+    //    and issues one LDS atomic), followed by the scalar bookkeeping of thread 0.
+    if (threadIdx.x < active) {
         sHit[threadIdx.x] = __hip_atomic_load(&state->slot[threadIdx.x].firstHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sSumSq[threadIdx.x] = 0;
+        sSumTotal[threadIdx.x] = 0;
+    }
     __syncthreads();
     for (uint32_t j = 0; j < active; ++j) {
         const uint32_t hit = sHit[j];
+        if (hit == kNoCluster) continue;  // uniform
+        uint32_t* rep = reps + (size_t)sSlot[j].rep * numBins;
+        const ClusterCount* add = table + (size_t)order[hit] * numBins;
+        uint32_t sq = 0, tot = 0;
+        for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
+            const uint32_t v = rep[i] + (uint32_t)add[i];
+            rep[i] = v;
+            if (binCounts(i, blockDim.x, liveWarps)) {
+                sq += v * v;
+                tot += v;
+            }
+        }
+        for (uint32_t w = lanes >> 1; w >= 1; w >>= 1) {  // `lanes` = 32 in a block's last, half-filled wave
+            sq += __shfl_xor(sq, w, 64);
+            tot += __shfl_xor(tot, w, 64);
+        }
+        if ((threadIdx.x & 63u) == 0) {
+            atomicAdd(&sSumSq[j], sq);
+            atomicAdd(&sSumTotal[j], tot);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < active) {
+        const uint32_t j = threadIdx.x, hit = sHit[j];
         const uint32_t cursor = sCursor[j], len = sLen[j], chunk = sSlot[j].chunk;
-        uint32_t newCursor = cursor, newChunk = chunk, newSq = sSlot[j].sq;
         if (hit != kNoCluster) {
-            newSq = absorb(reps + (size_t)sSlot[j].rep * numBins, table + (size_t)order[hit] * numBins, true);
-            if (threadIdx.x == 0) cluster[hit] = sSlot[j].id;
-            newCursor = hit + 1;
+            cluster[hit] = sSlot[j].id;
+            sSlot[j].sq = sSumSq[j];
+            sSlot[j].total = sSumTotal[j];
+            sSlot[j].cursor = hit + 1;
             // judging costs time even beside the hit, so the next pass looks twice as far as this hit was
             const uint32_t gap = 2u * (hit - cursor + 1u);
-            newChunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
+            sSlot[j].chunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
         } else if (len) {
-            newCursor = cursor + len;
-            if (len == chunk) newChunk = 4u * chunk > maxChunk ? maxChunk : 4u * chunk;  // not held back by the older cluster
+            sSlot[j].cursor = cursor + len;
+            if (len == chunk) sSlot[j].chunk = 4u * chunk > maxChunk ? maxChunk : 4u * chunk;  // not held back by the older one
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            sSlot[j].cursor = newCursor;
-            sSlot[j].chunk = newChunk;
-            sSlot[j].sq = newSq;
-            sSlot[j].firstHit = kNoCluster;
-        }
-        __syncthreads();
+        sSlot[j].firstHit = kNoCluster;
     }
+    __syncthreads();
     // 2. retire finished clusters (only the oldest can be finished: the others trail it)
     uint32_t retired = 0, floor = state->floor, freeReps = state->freeReps, nextId = state->nextId;
     while (retired < active && sSlot[retired].cursor >= rows) {
@@ -327,6 +453,7 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
                 c.chunk = 2u * kClusterMinChunk;
                 c.id = nextId;
                 c.sq = sq;
+                c.total = sTotal;
                 c.firstHit = kNoCluster;
                 c.scan = found + 1;
                 c.rep = r;
@@ -354,18 +481,25 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
 // first representative = the seed row's histogram; its sum of squares as in clusterPass
 __global__ void clusterInitRepresentative(const ClusterCount* __restrict__ seedRow, uint32_t* __restrict__ rep,
                                           uint32_t numBins, uint32_t liveWarps, ClusterState* __restrict__ state) {
-    __shared__ uint32_t total;
-    if (threadIdx.x == 0) total = 0;
+    __shared__ uint32_t total[2];
+    if (threadIdx.x < 2) total[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t sq = 0;
+    uint32_t sq = 0, tot = 0;
     for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
         const uint32_t v = seedRow[i];
         rep[i] = v;
-        if (binCounts(i, blockDim.x, liveWarps)) sq += v * v;
+        if (binCounts(i, blockDim.x, liveWarps)) {
+            sq += v * v;
+            tot += v;
+        }
     }
-    atomicAdd(&total, sq);
+    atomicAdd(&total[0], sq);
+    atomicAdd(&total[1], tot);
     __syncthreads();
-    if (threadIdx.x == 0) state->slot[0].sq = total;
+    if (threadIdx.x == 0) {
+        state->slot[0].sq = total[0];
+        state->slot[0].total = total[1];
+    }
 }
 
 }  // namespace bsmr

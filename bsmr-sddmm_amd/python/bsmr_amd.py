@@ -64,7 +64,7 @@ class ReorderingReport(C.Structure):
 
 class ClusterStats(C.Structure):
     _fields_ = [("elapsed_ms", C.c_float), ("passes", C.c_uint32), ("similarities", C.c_uint32),
-                ("threads_per_pair", C.c_uint32), ("table_bytes", C.c_uint64)]
+                ("exact_similarities", C.c_uint32), ("threads_per_pair", C.c_uint32), ("table_bytes", C.c_uint64)]
 
 
 class Timing(C.Structure):

@@ -143,7 +143,8 @@ int bsmr_plan_dense_choice(const bsmr_plan *plan, uint32_t K, uint32_t *group_si
 typedef struct bsmr_cluster_stats {
     float    elapsed_ms;        /* device time, uploads and downloads included        */
     uint32_t passes;            /* speculative passes launched that did work          */
-    uint32_t similarities;      /* (representative, row) pairs evaluated              */
+    uint32_t similarities;      /* (representative, row) pairs judged                 */
+    uint32_t exact_similarities;/* ... of which within 1e-4 of alpha (exact evaluation) */
     uint32_t threads_per_pair;  /* workgroup size = the reference's clustering block  */
     uint64_t table_bytes;       /* rows x bins histogram table                        */
 } bsmr_cluster_stats;
