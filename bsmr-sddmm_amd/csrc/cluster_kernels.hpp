@@ -41,7 +41,7 @@ constexpr uint32_t kNoCluster = 0xFFFFFFFFu;
 typedef uint16_t ClusterCount;
 constexpr uint32_t kClusterMinChunk = 32;
 
-constexpr uint32_t kClusterMaxActive = 16;
+constexpr uint32_t kClusterMaxActive = 32;
 
 struct ClusterSlot {
     uint32_t seed;      // position of the cluster's first row
@@ -177,7 +177,7 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
     __shared__ uint32_t sCursor[kClusterMaxActive], sLen[kClusterMaxActive], sStart[kClusterMaxActive + 1];
     __shared__ uint32_t sHit[kClusterMaxActive], sSumSq[kClusterMaxActive], sSumTotal[kClusterMaxActive];
     __shared__ ClusterSlot sSlot[kClusterMaxActive + 1];
-    // MANY only: items of this round within 1e-4 of alpha, (cluster << 28) | offset in its window
+    // MANY only: items of this round within 1e-4 of alpha, (cluster << 27) | offset in its window
     __shared__ uint32_t sNear[MANY ? 1024 : 1];
     __shared__ uint32_t sNearCount;
     if (state->done) return;  // uniform over the grid: the state only changes at the end of a pass
@@ -275,7 +275,7 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
                 }
                 if (lane == 0) {
                     if (hit) atomicMin(&state->slot[j].firstHit, pos);
-                    if (near) sNear[atomicAdd(&sNearCount, 1u)] = (j << 28) | (item - sStart[j]);
+                    if (near) sNear[atomicAdd(&sNearCount, 1u)] = (j << 27) | (item - sStart[j]);
                 }
             }
         }
@@ -283,7 +283,7 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
         // -- the near ones again, by the whole workgroup, in the reference's order of operations --
         const uint32_t nearCount = sNearCount;
         for (uint32_t n = 0; n < nearCount; ++n) {
-            const uint32_t j = sNear[n] >> 28, pos = sCursor[j] + (sNear[n] & 0x0FFFFFFFu);
+            const uint32_t j = sNear[n] >> 27, pos = sCursor[j] + (sNear[n] & 0x07FFFFFFu);
             const uint32_t row = order[pos];
             const float sim = similarityAsReference(reps + (size_t)sSlot[j].rep * numBins, sSlot[j].sq,
                                                     table + (size_t)row * numBins, rowSquares[row], numBins, shmA, shmB);
