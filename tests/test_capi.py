@@ -62,6 +62,10 @@ def test_argument_validation_without_gpu(engine):
     assert hip.bsmr_dev_free(None) == engine.OK
     assert hip.bsmr_memcpy_h2d(None, None, 0) == engine.OK
     assert hip.bsmr_memcpy_h2d(None, None, 8) == engine.ERR_INVALID_ARG
+    assert hip.bsmr_sddmm_batch(None, 32, None, None, None, 2, 0, None) == engine.ERR_INVALID_ARG
+    assert hip.bsmr_batched_transpose(4, 4, 1, None, None, None) == engine.ERR_INVALID_ARG
+    assert hip.bsmr_plan_sparse_choice(None, 32, 0, None, None) == engine.ERR_INVALID_ARG
+    assert hip.bsmr_cluster_rows(0, 4, 4, None, None, 16, 0.3, None, None, None, None) == engine.ERR_INVALID_ARG
 
 
 def test_no_device_is_an_error_code_not_a_crash(engine):
@@ -80,6 +84,10 @@ def test_no_device_is_an_error_code_not_a_crash(engine):
         engine.sddmm_operator(csr, 32, A, B)
     out = C.c_void_p()
     assert engine.hip().bsmr_dev_alloc(0, 64, C.byref(out)) == engine.ERR_NO_DEVICE
+    # the device clustering entry point reports the missing device; BSMR::rowReordering then uses the host path
+    st, perm, clusters, _ = engine.cluster_rows_device(rows, cols, ro, ci, 16, 0.3)
+    assert st == engine.ERR_NO_DEVICE and perm.size == 0
+    assert engine.Pipeline(csr, device=-1).num_clusters > 0
 
 
 def test_cli_contract(engine, tmp_path):
