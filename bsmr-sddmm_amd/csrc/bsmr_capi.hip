@@ -80,6 +80,8 @@ struct bsmr_plan {
     bool sparseFree = false;
     uint64_t foldedEntries = 0;    // entries of a small dense part that were moved to the residue
     bool convertPass = false;      // F16/BF16 calls start with the fp32 -> 16-bit pass over A and B
+    bool convertBOnly = false;     // no dense part: calls with enough work convert B alone, the residue rounds A while staging
+    uint64_t bOnlyWork = 0;        // ... residue entries x K from which that pays
     int denseBatch = 0;            // blocks per LDS batch at K = 128 (0 = default)
     bool useStream = true;         // streaming kernel for ungrouped plans (BSMR_DENSE_STREAM=0 disables)
 };
@@ -184,8 +186,8 @@ const DenseFormat& chooseFormat(const bsmr_plan* p, uint32_t K) {
 // --- launchers -------------------------------------------------------------
 template <int MODE>
 int launchConvert(const bsmr_plan* p, uint32_t K, const float* A, const float* B, uint16_t* A16,
-                  uint16_t* B16, hipStream_t s) {
-    const uint64_t nA8 = (uint64_t)p->M * K / 8, nB8 = (uint64_t)p->N * K / 8;
+                  uint16_t* B16, hipStream_t s, bool skipA = false) {
+    const uint64_t nA8 = skipA ? 0 : (uint64_t)p->M * K / 8, nB8 = (uint64_t)p->N * K / 8;
     const uint64_t total = nA8 + nB8;
     if (total == 0) return BSMR_OK;
     const uint64_t wgs = std::min<uint64_t>((total + bsmr::kThreads - 1) / bsmr::kThreads, 256 * 16);
@@ -394,10 +396,14 @@ int launchSparse(const bsmr_plan* p, uint32_t K, const float* A, const float* B,
 
 template <int LPE, int CPL, int MODE>
 int launchSparse16T(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
-                    hipStream_t s) {
+                    hipStream_t s, bool aFp32) {
     const size_t lds = (size_t)16 * (2u * K + bsmr::kSparseLdsPad16);
     const uint32_t wgs = p->numSparseItems;
-    if (p->sparseFree) {
+    if (aFp32) {  // only set when the panels fit LDS and the residue is in panel form
+        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, true, CPL, false, true>), dim3(wgs, g_batch.count),
+                           dim3(bsmr::kThreads), lds, s, A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow,
+                           p->sparseItems, P, g_batch);
+    } else if (p->sparseFree) {
         hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, false, CPL, true>), dim3(wgs, g_batch.count),
                            dim3(bsmr::kThreads), 0, s, A16, B16, K, p->entryRowId, p->entryCol, p->entryDst, p->entryRow,
                            p->sparseItems, P, g_batch);
@@ -412,20 +418,21 @@ int launchSparse16T(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const u
     return BSMR_OK;
 }
 
+// aFp32: A16 is the caller's fp32 A (plans that convert B alone)
 template <int MODE>
 int launchSparse16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
-                   hipStream_t s) {
+                   hipStream_t s, bool aFp32 = false) {
     if (p->numSparseItems == 0) return BSMR_OK;
     const SparseShape sh = sparseShape(p, K, true);
     switch (sh.lpe * 100 + sh.cpl) {
-    case 401: return launchSparse16T<4, 1, MODE>(p, K, A16, B16, P, s);  // K = 32
-    case 402: return launchSparse16T<4, 2, MODE>(p, K, A16, B16, P, s);  // K = 64
-    case 404: return launchSparse16T<4, 4, MODE>(p, K, A16, B16, P, s);  // K = 128
-    case 804: return launchSparse16T<8, 4, MODE>(p, K, A16, B16, P, s);  // K = 256
-    case 808: return launchSparse16T<8, 8, MODE>(p, K, A16, B16, P, s);  // K = 512
-    case 1600: return launchSparse16T<16, 0, MODE>(p, K, A16, B16, P, s);
-    case 400: return launchSparse16T<4, 0, MODE>(p, K, A16, B16, P, s);
-    default: return launchSparse16T<8, 0, MODE>(p, K, A16, B16, P, s);
+    case 401: return launchSparse16T<4, 1, MODE>(p, K, A16, B16, P, s, aFp32);  // K = 32
+    case 402: return launchSparse16T<4, 2, MODE>(p, K, A16, B16, P, s, aFp32);  // K = 64
+    case 404: return launchSparse16T<4, 4, MODE>(p, K, A16, B16, P, s, aFp32);  // K = 128
+    case 804: return launchSparse16T<8, 4, MODE>(p, K, A16, B16, P, s, aFp32);  // K = 256
+    case 808: return launchSparse16T<8, 8, MODE>(p, K, A16, B16, P, s, aFp32);  // K = 512
+    case 1600: return launchSparse16T<16, 0, MODE>(p, K, A16, B16, P, s, aFp32);
+    case 400: return launchSparse16T<4, 0, MODE>(p, K, A16, B16, P, s, aFp32);
+    default: return launchSparse16T<8, 0, MODE>(p, K, A16, B16, P, s, aFp32);
     }
 }
 
@@ -438,8 +445,15 @@ int checkCall(const bsmr_plan* p, uint32_t K, const void* A, const void* B, cons
     return BSMR_OK;
 }
 
-inline bool needsWorkspace(const bsmr_plan* p, int mode) {
-    return mode != BSMR_COMPUTE_F32 && p->convertPass;
+// all-sparse plan, residue entries x K large enough to repay a conversion pass over B (and the kernel boundary
+// after it): B alone is converted and the residue kernel rounds A's rows while it stages them in LDS
+inline bool convertsBOnly(const bsmr_plan* p, uint32_t K) {
+    return p->convertBOnly && (uint64_t)p->numSparseEntries * K * g_batch.count >= p->bOnlyWork &&
+           (size_t)16 * (2u * K + bsmr::kSparseLdsPad16) <= 64 * 1024;
+}
+
+inline bool needsWorkspace(const bsmr_plan* p, int mode, uint32_t K) {
+    return mode != BSMR_COMPUTE_F32 && (p->convertPass || convertsBOnly(p, K));
 }
 
 int reserve(bsmr_plan* p, uint32_t K) {
@@ -461,6 +475,17 @@ int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P
     int st = BSMR_OK;
     if (mode == BSMR_COMPUTE_F32) {
         if ((which & 2) && (st = launchDense32(p, K, A, B, P, s)) != BSMR_OK) return st;
+    } else if (convertsBOnly(p, K)) {
+        if (which & 1) {
+            st = mode == BSMR_COMPUTE_F16 ? launchConvert<0>(p, K, A, B, p->A16, p->B16, s, true)
+                                          : launchConvert<1>(p, K, A, B, p->A16, p->B16, s, true);
+            if (st != BSMR_OK) return st;
+        }
+        if (which & 4)
+            return mode == BSMR_COMPUTE_F16
+                       ? launchSparse16<0>(p, K, reinterpret_cast<const uint16_t*>(A), p->B16, P, s, true)
+                       : launchSparse16<1>(p, K, reinterpret_cast<const uint16_t*>(A), p->B16, P, s, true);
+        return BSMR_OK;
     } else if (p->convertInKernel) {
         if (which & 2) {
             st = mode == BSMR_COMPUTE_F16 ? launchDenseCvt<0>(p, K, A, B, P, s) : launchDenseCvt<1>(p, K, A, B, P, s);
@@ -706,6 +731,13 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         p->convertInKernel =
             cvt >= 0 ? cvt != 0 : (!bigResidue && pk.unionColumns * 16ull < ((uint64_t)d->M + d->N) * 6ull);
         p->convertPass = !p->convertInKernel && (pk.numBlocks != 0 || bigResidue);
+        // all-sparse plans: converting B alone costs half a pass plus a kernel boundary (~5 us), which pays from
+        // about 1e8 residue entries x K (Trefethen_20000 K = 512: 58 -> 38 us, cop20k-like K = 128: 48 -> 44 us;
+        // below that the fp32 residue wins, e.g. wathen100 K = 128: 11.6 vs 16.7 us)
+        // a residue of > 10 entries per operand row converts anyway: B alone is then always the better pass
+        p->bOnlyWork = bigResidue ? 0 : (uint64_t)envInt("BSMR_B_ONLY_WORK_M", 100) * 1000000ull;
+        p->convertBOnly = cvt < 0 && p->sparseLowp && pk.numBlocks == 0 && !pk.freeResidue && pk.numSparseEntries != 0 &&
+                          envInt("BSMR_B_ONLY", 1) != 0;
 
         st = uploadDense(p->fmt[0], pk, p->indexBytes);
         p->fmt[0].stageInLds = outputMode == 2;
@@ -788,7 +820,8 @@ int bsmr_plan_sparse_choice(const bsmr_plan* plan, uint32_t K, int mode, uint32_
                             uint32_t* low_precision) {
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
-    const bool lowp = mode != BSMR_COMPUTE_F32 && plan->sparseLowp && plan->convertPass && plan->numSparseItems;
+    const bool lowp = mode != BSMR_COMPUTE_F32 && plan->sparseLowp && plan->numSparseItems &&
+                      (plan->convertPass || convertsBOnly(plan, K));
     if (lanes_per_entry) *lanes_per_entry = (uint32_t)sparseShape(plan, K, lowp).lpe;
     if (low_precision) *low_precision = lowp ? 1u : 0u;
     return BSMR_OK;
@@ -798,7 +831,7 @@ int bsmr_plan_reserve(bsmr_plan* plan, uint32_t K) {
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     BSMR_HIP(hipSetDevice(plan->device));
-    if (!plan->convertPass) return BSMR_OK;
+    if (!plan->convertPass && !convertsBOnly(plan, K)) return BSMR_OK;
     return reserve(plan, K);
 }
 
@@ -807,7 +840,7 @@ int bsmr_sddmm(bsmr_plan* plan, uint32_t K, const float* A, const float* B, floa
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     BSMR_HIP(hipSetDevice(plan->device));
-    if (needsWorkspace(plan, mode) && (st = reserve(plan, K)) != BSMR_OK) return st;
+    if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;
     return runPieces(plan, K, A, B, P, mode, static_cast<hipStream_t>(stream), 7);
 }
 
@@ -819,18 +852,19 @@ int bsmr_sddmm_batch(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     if (num_batches > 65535u || (uint64_t)K * num_batches > 0xFFFFFFFFull) return BSMR_ERR_INVALID_ARG;
     BSMR_HIP(hipSetDevice(plan->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool lowp = needsWorkspace(plan, mode);
-    if (lowp) {
-        // the batches are contiguous, so one conversion pass covers all of them
-        if ((st = reserve(plan, K * num_batches)) != BSMR_OK) return st;
-        st = mode == BSMR_COMPUTE_F16 ? launchConvert<0>(plan, K * num_batches, A, B, plan->A16, plan->B16, s)
-                                      : launchConvert<1>(plan, K * num_batches, A, B, plan->A16, plan->B16, s);
-        if (st != BSMR_OK) return st;
-    }
     struct Restore {
         ~Restore() { g_batch = bsmr::Batch{0, 0, 0, 1}; }
     } restore;
     g_batch = bsmr::Batch{(uint64_t)plan->M * K, (uint64_t)plan->N * K, plan->nnz, num_batches};
+    if (needsWorkspace(plan, mode, K)) {
+        // the batches are contiguous, so one conversion pass covers all of them
+        if ((st = reserve(plan, K * num_batches)) != BSMR_OK) return st;
+        const bool skipA = convertsBOnly(plan, K);
+        st = mode == BSMR_COMPUTE_F16
+                 ? launchConvert<0>(plan, K * num_batches, A, B, plan->A16, plan->B16, s, skipA)
+                 : launchConvert<1>(plan, K * num_batches, A, B, plan->A16, plan->B16, s, skipA);
+        if (st != BSMR_OK) return st;
+    }
     return runPieces(plan, K, A, B, P, mode, s, 6);  // dense + residue, grid y = batch
 }
 
@@ -885,7 +919,7 @@ int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     if (st != BSMR_OK) return st;
     if (!out || iters <= 0 || warmup < 0) return BSMR_ERR_INVALID_ARG;
     BSMR_HIP(hipSetDevice(plan->device));
-    if (needsWorkspace(plan, mode) && (st = reserve(plan, K)) != BSMR_OK) return st;
+    if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BSMR_HIP(hipEventCreate(&e0));
@@ -908,7 +942,7 @@ int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     for (int i = 0; i < warmup && st == BSMR_OK; ++i) st = runPieces(plan, K, A, B, P, mode, s, 7);
     bsmr_timing t{};
     if (st == BSMR_OK) st = timeLoop(7, t.total_ms);
-    if (st == BSMR_OK && needsWorkspace(plan, mode)) st = timeLoop(1, t.convert_ms);
+    if (st == BSMR_OK && needsWorkspace(plan, mode, K)) st = timeLoop(1, t.convert_ms);
     if (st == BSMR_OK && plan->fmt[0].numItems) st = timeLoop(2, t.dense_ms);
     if (st == BSMR_OK && plan->numSparseItems) st = timeLoop(4, t.sparse_ms);
     (void)hipEventDestroy(e0);

@@ -805,13 +805,15 @@ __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
     }
 }
 
-template <int LPE, int MODE, bool A_IN_LDS, int CPL = 0, bool FREE = false>
+// A_FP32 (panel form with LDS staging only): A16 points at the caller's fp32 A and the panel's rows are rounded
+// while they are staged - plans without a dense part then convert B alone (half the conversion pass).
+template <int LPE, int MODE, bool A_IN_LDS, int CPL = 0, bool FREE = false, bool A_FP32 = false>
 __global__ void __launch_bounds__(kThreads)
 sparseEntriesLowp(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, uint32_t K,
                   const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ entryCol,
                   const uint32_t* __restrict__ entryDst, const uint8_t* __restrict__ entryRow,
                   const SparseItem* __restrict__ items, float* __restrict__ P, Batch batch) {
-    A16 += blockIdx.y * batch.strideA;  // batched call: problem blockIdx.y of a strided batch
+    A16 += blockIdx.y * batch.strideA * (A_FP32 ? 2u : 1u);  // batched call: problem blockIdx.y of a strided batch
     B16 += blockIdx.y * batch.strideB;
     P += blockIdx.y * batch.strideP;
     extern __shared__ __attribute__((aligned(16))) uint8_t panelA16[];
@@ -820,11 +822,29 @@ sparseEntriesLowp(const uint16_t* __restrict__ A16, const uint16_t* __restrict__
     const uint32_t ldsStride = 2u * K + kSparseLdsPad16;
 
     if constexpr (A_IN_LDS) {
+        static_assert(!A_FP32 || !FREE, "fp32 A is rounded while a panel is staged");
         for (uint32_t i = threadIdx.x; i < 16u * chunks; i += kThreads) {
             const uint32_t row = i / chunks, q = i - row * chunks;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(
-                A16 + (size_t)panelRows[item.panel * 16u + row] * K + q * 8u);
-            *reinterpret_cast<u32x4*>(panelA16 + row * ldsStride + q * 16u) = v;
+            const size_t at = (size_t)panelRows[item.panel * 16u + row] * K + q * 8u;
+            if constexpr (A_FP32) {
+                const float* src = reinterpret_cast<const float*>(A16) + at;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
+                if constexpr (MODE == 0) {
+                    f16x8 o;
+                    o[0] = (_Float16)lo[0]; o[1] = (_Float16)lo[1]; o[2] = (_Float16)lo[2]; o[3] = (_Float16)lo[3];
+                    o[4] = (_Float16)hi[0]; o[5] = (_Float16)hi[1]; o[6] = (_Float16)hi[2]; o[7] = (_Float16)hi[3];
+                    *reinterpret_cast<f16x8*>(panelA16 + row * ldsStride + q * 16u) = o;
+                } else {
+                    bf16x8 o;
+                    o[0] = (__bf16)lo[0]; o[1] = (__bf16)lo[1]; o[2] = (__bf16)lo[2]; o[3] = (__bf16)lo[3];
+                    o[4] = (__bf16)hi[0]; o[5] = (__bf16)hi[1]; o[6] = (__bf16)hi[2]; o[7] = (__bf16)hi[3];
+                    *reinterpret_cast<bf16x8*>(panelA16 + row * ldsStride + q * 16u) = o;
+                }
+            } else {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(A16 + at);
+                *reinterpret_cast<u32x4*>(panelA16 + row * ldsStride + q * 16u) = v;
+            }
         }
         __syncthreads();
     }

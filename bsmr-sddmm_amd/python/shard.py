@@ -191,5 +191,5 @@ def run_sharded(eng, torch, dist, dev, rank, world, make_pattern, K, alpha, delt
         "plan_build_s": round(plan_s, 3),
         # this rank's shard, for the caller's roofline (used on rank 0)
         "rank0": {"kernels_ms": kt, "pattern": (lrows, cols, lro, lci), "dense_tiles": pipe.dense_choice(K)["tiles"],
-                  "sparse_lowp": bool(pipe.plan_stats()["sparse_lowp"])},
+                  "sparse_lowp": bool(pipe.sparse_choice(K, mode)["low_precision"])},
     }

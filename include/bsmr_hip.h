@@ -95,7 +95,8 @@ typedef struct bsmr_plan_stats {
     uint32_t grouped_group_size;
     uint64_t grouped_dense_tiles;
     uint64_t grouped_union_columns;
-    uint64_t sparse_lowp;             /* 1: in the F16/BF16 modes the residue reads the converted operands too */
+    uint64_t sparse_lowp;             /* 1: in the F16/BF16 modes the residue reads the converted operands too (for every K;
+                                       * bsmr_plan_sparse_choice reports calls that do so from a K upwards) */
     uint64_t folded_dense_entries;    /* entries of a small dense part (RPHM) that the plan computes with the residue */
     uint64_t free_residue;            /* 1: residue entries run in global column order, not per panel */
 } bsmr_plan_stats;
