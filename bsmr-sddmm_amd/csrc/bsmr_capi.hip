@@ -18,6 +18,7 @@
 
 #include "cluster_kernels.hpp"
 #include "plan_pack.hpp"
+#include "plan_promote.hpp"
 #include "sddmm_kernels.hpp"
 
 using bsmr::DenseItem;
@@ -79,6 +80,7 @@ struct bsmr_plan {
     uint32_t* entryRowId = nullptr;  // free-form residue: row id per entry (panelRows / entryRow unused)
     bool sparseFree = false;
     uint64_t foldedEntries = 0;    // entries of a small dense part that were moved to the residue
+    uint64_t promotedEntries = 0;  // residue entries of the RPHM that the plan computes as extra dense blocks
     bool convertPass = false;      // F16/BF16 calls start with the fp32 -> 16-bit pass over A and B
     bool convertBOnly = false;     // no dense part: calls with enough work convert B alone, the residue rounds A while staging
     uint64_t bOnlyWork = 0;        // ... residue entries x K from which that pays
@@ -631,12 +633,28 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         bsmr_rphm_desc folded;
         std::vector<uint32_t> fBlockOffsets, fSparseOffsets, fValues, fRows, fCols;
         uint64_t foldedEntries = 0;
-        const uint64_t denseEntries = d->nnz >= numSparse ? d->nnz - numSparse : 0;
         bool offsetsOk = true;  // malformed offsets are left to packPlan's validation
         for (uint32_t q = 0; q < P && offsetsOk; ++q)
             offsetsOk = d->block_offsets[q] <= d->block_offsets[q + 1] &&
                         d->sparse_value_offsets[q] <= d->sparse_value_offsets[q + 1];
-        if (offsetsOk && numBlocks && denseEntries < (uint64_t)envInt("BSMR_FOLD_DENSE_BELOW", 32768)) {
+        // A panel whose residue averages >= 20 entries per 16-column block is cheaper on the MFMA path
+        // (plan_promote.hpp; mycielskian15 alpha = delta = 0.3, K = 128: 66.8 -> 48.1 us).  A plan without a
+        // dense part only changes when a million entries move: the first dense block brings the conversion pass
+        // over A and a second launch with it (wathen100 K = 128, 227k entries forced over: 11.6 -> 19 us).
+        bsmr::PromotedRphm promoted;
+        uint64_t promotedEntries = 0;
+        const uint64_t foldBelow = (uint64_t)std::max(0, envInt("BSMR_FOLD_DENSE_BELOW", 32768));
+        if (offsetsOk && numSparse && (d->sparse_values && d->sparse_relative_rows && d->sparse_col_indices) &&
+            bsmr::promoteSparseBlocks(*d, (uint32_t)std::max(0, envInt("BSMR_PROMOTE_AVERAGE", 20)),
+                                      (uint64_t)envInt("BSMR_PROMOTE_MIN_ENTRIES_K", 1000) * 1000ull, foldBelow, promoted)) {
+            // (a dense part that would still be folded below stays as the RPHM has it)
+            if (d->nnz - promoted.desc.sparse_value_offsets[P] >= foldBelow) {
+                d = &promoted.desc;
+                promotedEntries = promoted.promotedEntries;
+            }
+        }
+        const uint64_t denseEntries = d->nnz >= d->sparse_value_offsets[P] ? d->nnz - d->sparse_value_offsets[P] : 0;
+        if (offsetsOk && d->block_offsets[P] && denseEntries < foldBelow) {
             struct Entry {
                 uint32_t col, row, value;
             };
@@ -717,6 +735,7 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         p->numSparseEntries = pk.numSparseEntries;
         p->numSparseItems = (uint32_t)pk.sparseItems.size();
         p->foldedEntries = foldedEntries;
+        p->promotedEntries = promotedEntries;
         p->sparseLowp = envInt("BSMR_SPARSE_LOWP", 1) != 0;
         p->sparseLpe = envInt("BSMR_SPARSE_LPE", 0);
         if (p->sparseLpe != 4 && p->sparseLpe != 8 && p->sparseLpe != 16) p->sparseLpe = 0;
@@ -802,6 +821,7 @@ int bsmr_plan_get_stats(const bsmr_plan* p, bsmr_plan_stats* out) {
     out->grouped_union_columns = p->fmt[1].unionColumns;
     out->sparse_lowp = p->sparseLowp && p->convertPass && p->numSparseItems ? 1 : 0;
     out->folded_dense_entries = p->foldedEntries;
+    out->promoted_sparse_entries = p->promotedEntries;
     out->free_residue = p->sparseFree ? 1 : 0;
     return BSMR_OK;
 }
@@ -824,6 +844,18 @@ int bsmr_plan_sparse_choice(const bsmr_plan* plan, uint32_t K, int mode, uint32_
                       (plan->convertPass || convertsBOnly(plan, K));
     if (lanes_per_entry) *lanes_per_entry = (uint32_t)sparseShape(plan, K, lowp).lpe;
     if (low_precision) *low_precision = lowp ? 1u : 0u;
+    return BSMR_OK;
+}
+
+int bsmr_plan_dense_flags(const bsmr_plan* plan, uint8_t* flags_host) {
+    if (!plan || (!flags_host && plan->nnz)) return BSMR_ERR_INVALID_ARG;
+    BSMR_HIP(hipSetDevice(plan->device));
+    std::fill(flags_host, flags_host + plan->nnz, (uint8_t)1);
+    if (plan->numSparseEntries == 0) return BSMR_OK;
+    std::vector<uint32_t> dst(plan->numSparseEntries);
+    BSMR_HIP(hipMemcpy(dst.data(), plan->entryDst, dst.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t v : dst)
+        if (v < plan->nnz) flags_host[v] = 0;
     return BSMR_OK;
 }
 

@@ -51,7 +51,8 @@ class PlanStats(C.Structure):
                 ("num_dense_tiles", C.c_uint64), ("union_columns", C.c_uint64),
                 ("grouped_group_size", C.c_uint32), ("grouped_dense_tiles", C.c_uint64),
                 ("grouped_union_columns", C.c_uint64), ("sparse_lowp", C.c_uint64),
-                ("folded_dense_entries", C.c_uint64), ("free_residue", C.c_uint64)]
+                ("folded_dense_entries", C.c_uint64), ("free_residue", C.c_uint64),
+                ("promoted_sparse_entries", C.c_uint64)]
 
 
 class ReorderingReport(C.Structure):
@@ -98,6 +99,7 @@ HIP_SYMBOLS = {
     "bsmr_plan_dense_choice": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64)]),
     "bsmr_plan_reserve": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "bsmr_plan_dense_flags": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsmr_sddmm": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                              C.c_void_p]),
     "bsmr_sddmm_timed": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -325,6 +327,12 @@ class Pipeline:
         s = PlanStats()
         _check(hip().bsmr_plan_get_stats(self.plan, C.byref(s)), "bsmr_plan_get_stats")
         return {k: getattr(s, k) for k, _ in PlanStats._fields_}
+
+    def dense_flags(self) -> np.ndarray:
+        """uint8 per stored entry (CSR order): 1 = computed by the dense (MFMA) path of the plan, 0 = residue."""
+        flags = np.zeros(self.csr.nnz, dtype=np.uint8)
+        _check(hip().bsmr_plan_dense_flags(self.plan, flags.ctypes.data_as(C.c_void_p)), "dense_flags")
+        return flags
 
     def sparse_choice(self, K: int, mode=COMPUTE_F16) -> dict:
         lanes, lowp = C.c_uint32(0), C.c_uint32(0)

@@ -99,6 +99,7 @@ typedef struct bsmr_plan_stats {
                                        * bsmr_plan_sparse_choice reports calls that do so from a K upwards) */
     uint64_t folded_dense_entries;    /* entries of a small dense part (RPHM) that the plan computes with the residue */
     uint64_t free_residue;            /* 1: residue entries run in global column order, not per panel */
+    uint64_t promoted_sparse_entries; /* residue entries (RPHM) that the plan computes as extra dense blocks */
 } bsmr_plan_stats;
 
 /* Kernel timings of the last bsmr_sddmm_timed call, milliseconds per iteration. */
@@ -159,6 +160,12 @@ int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const uint32_t *
  * oracle/sddmm_oracle.c takes the same number) and whether it reads the fp16/bf16 copies. */
 int bsmr_plan_sparse_choice(const bsmr_plan *plan, uint32_t K, int compute_mode,
                             uint32_t *lanes_per_entry, uint32_t *low_precision);
+
+/* Which kernel computes each stored entry: flags_host[i] (i = CSR index, nnz bytes, host memory) becomes 1
+ * when the plan computes entry i on the dense (MFMA) path and 0 when the residue kernel does.  This is the
+ * reference's dense / sparse split (BSMR::blockValues / sparseValues) after the plan's own moves
+ * (folded_dense_entries, promoted_sparse_entries); the accuracy contract of an entry follows its path. */
+int bsmr_plan_dense_flags(const bsmr_plan *plan, uint8_t *flags_host);
 
 /* Grow the plan's operand workspace for inner dimension K now (otherwise it
  * grows on first use, which allocates and therefore must not happen inside a

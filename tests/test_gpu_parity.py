@@ -35,12 +35,19 @@ def run_hip(eng, pipe, K, A, B, mode):
 
 
 def dense_flags(pipe):
-    """1 for CSR entries computed by the dense-block path, 0 for the sparse residue."""
-    flags = np.zeros(pipe.csr.nnz, dtype=np.uint8)
-    if pipe.plan_stats()["folded_dense_entries"]:
-        return flags                       # a small dense part is computed with the residue
+    """1 for CSR entries computed by the dense-block path of the plan, 0 for the sparse residue: the RPHM's
+    split after the plan's own moves (a small dense part folded into the residue, residue blocks promoted)."""
+    flags = pipe.dense_flags()
+    st = pipe.plan_stats()
+    rphm = np.zeros(pipe.csr.nnz, dtype=np.uint8)
     bv = pipe.array("blockValues")
-    flags[bv[bv != 0xFFFFFFFF]] = 1
+    rphm[bv[bv != 0xFFFFFFFF]] = 1
+    if st["folded_dense_entries"]:
+        assert not flags.any() and st["folded_dense_entries"] == int(rphm.sum())
+    else:
+        assert (flags >= rphm).all()                                  # dense entries stay dense
+        assert int(flags.sum()) - int(rphm.sum()) == st["promoted_sparse_entries"]
+    assert int(flags.sum()) == st["num_dense_entries"] and int((flags == 0).sum()) == st["num_sparse_entries"]
     return flags
 
 
@@ -347,9 +354,13 @@ def test_suitesparse_patterns_match_reference_split_and_cpu(engine, oracle, name
     st = pipe.plan_stats()
     assert pipe.num_clusters == run["bsmr_numClusters"]
     assert pipe.evaluate()["num_dense_blocks"] == run["bsmr_numDenseBlock"]
-    assert st["num_dense_blocks"] == int(pipe.array("blockOffsets")[-1])
-    assert st["num_dense_entries"] == run["bsmr_numDenseData"]
-    assert st["num_sparse_entries"] == run["bsmr_numSparseData"]
+    assert int(pipe.array("blockOffsets")[-1]) == run["bsmr_numDenseBlock"]
+    # the device plan moves entries between its two kernels on top of that split, never across the logged totals
+    moved = st["promoted_sparse_entries"] - st["folded_dense_entries"]
+    assert st["num_dense_entries"] == run["bsmr_numDenseData"] + moved
+    assert st["num_sparse_entries"] == run["bsmr_numSparseData"] - moved
+    if not moved:
+        assert st["num_dense_blocks"] == run["bsmr_numDenseBlock"]
 
 
 def test_hipgraph_capture_and_replay(engine, oracle):
@@ -502,7 +513,8 @@ def test_small_dense_parts_are_folded(engine, oracle, monkeypatch):
         assert st["dense_work_items"] == 0
     monkeypatch.setenv("BSMR_FOLD_DENSE_BELOW", "100")
     pipe = check_case(engine, oracle, rows, cols, ro, ci, 64, 0.2, 0.1, 0)
-    assert pipe.plan_stats()["folded_dense_entries"] == 0 and pipe.plan_stats()["num_dense_entries"] == dense_in_rphm
+    st = pipe.plan_stats()
+    assert st["folded_dense_entries"] == 0 and st["num_dense_entries"] == dense_in_rphm + st["promoted_sparse_entries"]
 
 
 def test_free_form_residue_equals_panel_form(engine, oracle, monkeypatch):
@@ -565,3 +577,37 @@ def test_b_alone_conversion_needs_enough_work(engine, oracle, monkeypatch):
     monkeypatch.setenv("BSMR_B_ONLY_WORK_M", "1")
     pipe = check_case(engine, oracle, rows, cols, ro, ci, K, 0.3, 0.3, 0)
     assert pipe.sparse_choice(K, 0)["low_precision"] == 1 and pipe.sparse_choice(K, 2)["low_precision"] == 0
+
+
+def test_residue_blocks_are_promoted_to_dense_blocks(engine, oracle, monkeypatch):
+    """A panel whose residue columns, cut into 16-column blocks, average >= BSMR_PROMOTE_AVERAGE entries per block
+    gives its residue to the dense path of the plan: the RPHM and its statistics stay as the reference defines
+    them, every entry is still written exactly once, and with the threshold at 0 the plan is the RPHM's own split."""
+    rows, cols, ro, ci = synth.community_graph(n=600, avg_degree=60, communities=5, seed=11)
+    K = 128
+    A = engine.make_data(rows * K, 5489)
+    B = engine.make_data(cols * K, 5490)
+    monkeypatch.setenv("BSMR_PROMOTE_AVERAGE", "0")
+    plain = check_case(engine, oracle, rows, cols, ro, ci, K, 0.2, 0.3, 0)
+    st0 = plain.plan_stats()
+    assert st0["promoted_sparse_entries"] == 0 and st0["num_sparse_entries"] > 0
+    rphm_dense = int((plain.array("blockValues") != 0xFFFFFFFF).sum())
+    assert st0["num_dense_entries"] == rphm_dense
+    for level in ("20", "8", "1"):
+        monkeypatch.setenv("BSMR_PROMOTE_AVERAGE", level)
+        for mode in (0, 1, 2):
+            pipe = check_case(engine, oracle, rows, cols, ro, ci, K, 0.2, 0.3, mode)
+        st = pipe.plan_stats()
+        assert st["num_dense_entries"] == rphm_dense + st["promoted_sparse_entries"]
+        if level == "20" and st["promoted_sparse_entries"] == 0:
+            continue                                                  # no panel of this graph is that full
+        assert st["promoted_sparse_entries"] > 0
+        assert st["num_dense_blocks"] > st0["num_dense_blocks"]
+        assert pipe.evaluate() == plain.evaluate()                    # the reference-visible split is untouched
+        flags = pipe.dense_flags()
+        if level == "1":
+            assert st["num_sparse_entries"] == 0     # every panel qualifies: no residue is left
+        got = run_hip(engine, pipe, K, A, B, 2)
+        want = run_hip(engine, plain, K, A, B, 2)
+        same_path = flags == plain.dense_flags()
+        assert np.array_equal(got[same_path], want[same_path])       # fp32 mode: untouched entries bit for bit
