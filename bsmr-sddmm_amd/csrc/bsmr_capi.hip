@@ -646,7 +646,8 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         const uint64_t foldBelow = (uint64_t)std::max(0, envInt("BSMR_FOLD_DENSE_BELOW", 32768));
         if (offsetsOk && numSparse && (d->sparse_values && d->sparse_relative_rows && d->sparse_col_indices) &&
             bsmr::promoteSparseBlocks(*d, (uint32_t)std::max(0, envInt("BSMR_PROMOTE_AVERAGE", 20)),
-                                      (uint64_t)envInt("BSMR_PROMOTE_MIN_ENTRIES_K", 1000) * 1000ull, foldBelow, promoted)) {
+                                      (uint64_t)envInt("BSMR_PROMOTE_MIN_ENTRIES_K", 1000) * 1000ull, foldBelow,
+                                      (uint32_t)std::max(0, envInt("BSMR_PROMOTE_COLUMN_DEGREE", 32)), promoted)) {
             // (a dense part that would still be folded below stays as the RPHM has it)
             if (d->nnz - promoted.desc.sparse_value_offsets[P] >= foldBelow) {
                 d = &promoted.desc;

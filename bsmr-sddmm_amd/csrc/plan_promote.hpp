@@ -35,12 +35,17 @@ struct PromotedRphm {
 // Returns true and fills `out` when blocks were promoted.  `minAverage`: entries per 16-column block that a
 // panel's residue needs on average; `minGain`: promoted entries below which a plan WITHOUT a dense part (fewer than `smallDense` dense entries: the plan folds those into the
 // residue) is left alone - a first dense block brings the conversion pass and a second launch with it.
+// `minColumnDegree`: stored entries per column of S (nnz / N) the pattern needs at all - the dense kernel gathers 16
+// columns of B per block and is only cheap when those columns are reused from cache by other panels (graph / ML
+// patterns: mycielskian15 113, nips-like 60, Bernoulli 4096^2 410; mesh / FEM patterns: cop20k-like 11, wathen100 8,
+// Trefethen 14 - their blocks cost 0.58 ns instead of 0.29 and the conversion of A is paid on top).
 // Malformed input is left to packPlan's validation (returns false).
 inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, uint64_t minGain, uint64_t smallDense,
-                                PromotedRphm& out) {
+                                uint32_t minColumnDegree, PromotedRphm& out) {
     const uint32_t P = in.num_row_panels;
     const uint64_t numSparse = in.sparse_value_offsets[P];
     if (minAverage == 0 || numSparse == 0 || numSparse > 0xFFFFFFF0ull) return false;
+    if ((uint64_t)in.nnz < (uint64_t)minColumnDegree * in.N) return false;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
 
     // pass 1, per panel: columns of the residue by descending count (ties: ascending id, the reference's
@@ -66,11 +71,14 @@ inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, u
                 if (in.sparse_col_indices[s0 + i] >= in.N || in.sparse_relative_rows[s0 + i] >= 16) bad[w] = 1;
             }
             if (bad[w]) return;
-            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-                return in.sparse_col_indices[x] != in.sparse_col_indices[y]
-                           ? in.sparse_col_indices[x] < in.sparse_col_indices[y]
-                           : x < y;
-            });
+            bool sorted = true;  // the host pipeline's residue is already in column order
+            for (uint32_t i = s0 + 1; i < s1 && sorted; ++i) sorted = in.sparse_col_indices[i - 1] <= in.sparse_col_indices[i];
+            if (!sorted)
+                std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+                    return in.sparse_col_indices[x] != in.sparse_col_indices[y]
+                               ? in.sparse_col_indices[x] < in.sparse_col_indices[y]
+                               : x < y;
+                });
             columns.clear();
             for (uint32_t i = 0; i < order.size(); ++i) {
                 const uint32_t c = in.sparse_col_indices[order[i]];

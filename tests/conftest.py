@@ -27,7 +27,8 @@ def pytest_configure(config):
 def _ensure_built():
     need = [REPO / "bsmr-sddmm_amd" / "lib" / "libbsmr_hip.so",
             REPO / "bsmr-sddmm_amd" / "lib" / "libbsmr_host.so",
-            REPO / "oracle" / "liboracle.so"]
+            REPO / "oracle" / "liboracle.so",
+            REPO / "tests" / "native" / "libplancheck.so"]
     if all(p.exists() for p in need):
         return
     import __graft_entry__

@@ -1,0 +1,100 @@
+"""The host side of bsmr_plan_create without a GPU: residue promotion (csrc/plan_promote.hpp) and packing
+(csrc/plan_pack.hpp) on RPHM arrays of the host pipeline, through tests/native/plancheck.hip, which checks that
+every stored entry still has exactly one place - a cell of a block at its own row and column, or the residue."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import synth
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def plancheck(engine):
+    lib = C.CDLL(str(REPO / "tests" / "native" / "libplancheck.so"))
+    lib.plancheck_promote.restype = C.c_int
+    lib.plancheck_promote.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+
+    def run(rows, cols, ro, ci, alpha, delta, min_average=20, min_entries=1_000_000, small_dense=32768, column_degree=32):
+        csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+        pipe = engine.Pipeline(csr, alpha=alpha, delta=delta, device=-1)
+        arrays = pipe.arrays()
+        keep = {k: np.ascontiguousarray(arrays[k], dtype=np.uint32) for k in
+                ("reorderedRows", "denseCols", "blockOffsets", "blockValues", "sparseValueOffsets",
+                 "sparseValues", "sparseRelativeRows", "sparseColIndices")}
+        d = engine.RphmDesc()
+        d.M, d.N, d.nnz = rows, cols, csr.nnz
+        d.num_nonzero_rows = keep["reorderedRows"].size
+        d.num_row_panels = keep["blockOffsets"].size - 1
+        cast = lambda a: a.ctypes.data_as(engine.u32p)
+        d.reordered_rows, d.dense_cols = cast(keep["reorderedRows"]), cast(keep["denseCols"])
+        d.block_offsets, d.block_values = cast(keep["blockOffsets"]), cast(keep["blockValues"])
+        d.sparse_value_offsets, d.sparse_values = cast(keep["sparseValueOffsets"]), cast(keep["sparseValues"])
+        d.sparse_relative_rows, d.sparse_col_indices = cast(keep["sparseRelativeRows"]), cast(keep["sparseColIndices"])
+        out = (C.c_uint64 * 10)()
+        rc = lib.plancheck_promote(C.byref(d), min_average, min_entries, small_dense, column_degree, out)
+        names = ("promoted", "promoted_entries", "promoted_blocks", "blocks", "residue", "pack_status", "packed_dense",
+                 "packed_residue", "promote_us", "pack_us")
+        res = dict(zip(names, (int(v) for v in out)))
+        res["rphm_dense"] = int(csr.nnz - keep["sparseValues"].size)
+        res["rphm_blocks"] = int(keep["blockOffsets"][-1])
+        res["nnz"] = csr.nnz
+        return rc, res
+    return run
+
+
+@pytest.mark.parametrize("min_average", [1, 8, 20, 40])
+@pytest.mark.parametrize("delta", [0.05, 0.3, 1.1])
+def test_promotion_keeps_every_entry_exactly_once(plancheck, min_average, delta):
+    rows, cols, ro, ci = synth.community_graph(n=900, avg_degree=70, communities=6, seed=5)
+    rc, r = plancheck(rows, cols, ro, ci, 0.2, delta, min_average=min_average, min_entries=1000, small_dense=100,
+                      column_degree=0)
+    assert rc == 0, f"invariant {rc} violated: {r}"
+    assert r["pack_status"] == 0
+    assert r["packed_dense"] + r["packed_residue"] == r["nnz"]
+    assert r["packed_dense"] == r["rphm_dense"] + r["promoted_entries"]
+    assert r["blocks"] == r["rphm_blocks"] + r["promoted_blocks"]
+    if min_average == 1 and (r["rphm_dense"] >= 100 or r["nnz"] - r["rphm_dense"] >= 1000):
+        assert r["promoted"] == 1 and r["residue"] == 0          # every panel qualifies
+
+
+def test_promotion_rules(plancheck):
+    """Which plans change: a hybrid plan gives well-filled panels to the dense path and the rest too when little is
+    left; a plan without a dense part only when at least `min_entries` entries move; threshold 0 switches it off."""
+    rows, cols, ro, ci = synth.mycielskian_pattern(11)            # 1535 rows, hub columns shared by all panels
+    rc, r = plancheck(rows, cols, ro, ci, 0.3, 0.3, small_dense=10_000)
+    assert rc == 0 and r["rphm_dense"] > 10_000 and r["promoted"] == 1
+    assert r["residue"] == 0 and r["packed_dense"] == r["nnz"]    # the whole residue follows
+    rc, off = plancheck(rows, cols, ro, ci, 0.3, 0.3, min_average=0)
+    assert rc == 0 and off["promoted"] == 0 and off["packed_dense"] == off["rphm_dense"]
+    # all-sparse plans: below the entry threshold nothing moves, above it everything that qualifies does
+    rc, r = plancheck(rows, cols, ro, ci, 0.3, 1.1)
+    assert rc == 0 and r["rphm_dense"] == 0 and r["promoted"] == 0 and r["packed_residue"] == r["nnz"]
+    rc, r = plancheck(rows, cols, ro, ci, 0.3, 1.1, min_entries=50_000)
+    assert rc == 0 and r["promoted"] == 1 and r["promoted_entries"] >= 50_000
+    # mesh-like patterns (11 entries per column of S: no reuse of a gathered column) stay in the residue
+    rows, cols, ro, ci = synth.banded_mesh_like(n=20000, nnz=220000, seed=7)
+    rc, r = plancheck(rows, cols, ro, ci, 0.3, 0.3, min_entries=1000)
+    assert rc == 0 and r["promoted"] == 0
+    rc, r = plancheck(rows, cols, ro, ci, 0.3, 0.3, min_entries=1000, column_degree=0)
+    assert rc == 0 and r["promoted"] == 1                        # (their panels do fill 20 per block)
+
+
+def test_promotion_with_repeated_entries(plancheck):
+    """A CSR row may hold the same column twice: a block cell takes one copy, the other stays in the residue."""
+    rows, cols = 64, 48
+    rng = np.random.default_rng(3)
+    ci, ro = [], [0]
+    for _ in range(rows):
+        c = np.sort(rng.choice(cols, size=20, replace=False))
+        c = np.sort(np.concatenate([c, c[:3]]))                   # three repeated columns per row
+        ci.extend(c.tolist())
+        ro.append(len(ci))
+    rc, r = plancheck(rows, cols, np.array(ro, dtype=np.uint32), np.array(ci, dtype=np.uint32), 0.3, 1.1,
+                      min_average=1, min_entries=10, small_dense=10, column_degree=0)
+    assert rc == 0, r
+    assert r["promoted"] == 1 and r["packed_dense"] + r["packed_residue"] == r["nnz"]
+    assert r["residue"] == 3 * rows                               # the second copies
