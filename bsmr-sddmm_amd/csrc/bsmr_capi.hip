@@ -52,9 +52,9 @@ struct bsmr_plan {
     uint32_t M = 0, N = 0, nnz = 0, numPanels = 0;
 
     // Dense part.  fmt[0] is always present when the matrix has dense blocks;
-    // fmt[1] (4 panels per group) is built in addition when grouping removes at
-    // least a quarter of the B column gathers, and is used for calls whose
-    // ungrouped gather would exceed kGroupedGatherBytes.
+    // fmt[1] (4 panels per group) is built in addition when grouping cuts the B
+    // column gathers 2.5x or more, and is used for calls whose ungrouped gather
+    // would exceed kGroupedGatherBytes.
     DenseFormat fmt[2];
     uint64_t numDenseEntries = 0;
 
@@ -93,7 +93,7 @@ namespace {
 // Measured on MI355X (profiles/r01_dense_ablation.md): grouping 4 panels loses at
 // 88 MB of ungrouped B gather (nips-like K=128: 14.2 vs 18.9 us) and wins at 353 MB
 // (nips-like K=512: 58.9 vs 45.1 us) and 876 MB (4096^2 10 % K=512: 103 vs 39.8 us).
-constexpr uint64_t kGroupedGatherBytes = 200ull << 20;
+constexpr uint64_t kGroupedGatherBytes = 400ull << 20;
 
 thread_local std::string g_lastHipError;
 // batch of the call being launched on this thread (bsmr_sddmm_batch sets it for the duration of the call)
@@ -176,11 +176,14 @@ int uploadDense(DenseFormat& f, const bsmr::PackedPlan& pk, uint64_t& bytes) {
 
 // Dense format for a call with inner dimension K.
 const DenseFormat& chooseFormat(const bsmr_plan* p, uint32_t K) {
-    // grouped when the ungrouped gather is large AND grouping at least halves it (measured at K = 512,
-    // ungrouped streaming kernel vs grouped: nips-like 1.94x fewer columns 31.7 vs 34.3 us, mycielskian15
-    // 1.6x 39.6 vs 57.4, 4096^2 Bernoulli(0.1) delta=0.1 2.09x 39.3 vs 35.1, delta=0 3.26x 62.4 vs 35.5)
+    // grouped when the ungrouped gather is large AND grouping cuts it by 2.5x or more: the streaming kernel
+    // gathers at 13-15 TB/s, the grouped (LDS-staged) kernel at 5-7 TB/s of its smaller volume.  Measured,
+    // ungrouped vs grouped dense kernel in us (tools/format_lab.py):
+    //   mycielskian15, residue promoted, 2.30x fewer columns: K=128 34.6 vs 41.0, K=256 62.1 vs 79.9, K=512 121 vs 119
+    //   mycielskian14, 2.45x: K=256 27.2 vs 39.9, K=512 48.8 vs 58.4       nips-like, 1.94x: K=512 31.7 vs 34.3
+    //   4096^2 Bernoulli(0.1), 3.26x: K=128 (218 MB) 17.9 vs 18.9, K=256 (437 MB) 32.5 vs 25.1, K=512 62.7 vs 36.9
     if (p->fmt[1].H && p->fmt[0].unionColumns * (uint64_t)K * 2ull >= kGroupedGatherBytes &&
-        p->fmt[0].unionColumns >= 2 * p->fmt[1].unionColumns)
+        p->fmt[0].unionColumns * 2 >= 5 * p->fmt[1].unionColumns)
         return p->fmt[1];
     return p->fmt[0];
 }
@@ -771,9 +774,9 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         if (st == BSMR_OK) st = upload(p->sparseItems, pk.sparseItems, p->indexBytes);
 
         // second dense format (4 panels per group) for gather-bound calls
-        // (only when it could ever be chosen: chooseFormat wants at least half the ungrouped columns gone)
+        // (only when it could ever be chosen: chooseFormat wants the ungrouped columns cut 2.5x)
         if (st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8 &&
-            pk.unionColumns >= 2 * bsmr::countUnionColumns(d, 4)) {
+            pk.unionColumns * 2 >= 5 * bsmr::countUnionColumns(d, 4)) {
             bsmr::PackedPlan pk4;
             opt.group = 4;
             opt.blocksPerItem = envInt("BSMR_DENSE_BLOCKS_PER_WG", 32);

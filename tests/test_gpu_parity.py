@@ -188,15 +188,16 @@ def test_plan_knobs(engine, oracle, monkeypatch, knobs, K):
 
 def test_grouped_format_is_chosen_for_gather_bound_calls(engine, oracle):
     """A plan keeps a second dense format (4 panels per group) and uses it when the ungrouped
-    B gather would exceed ~200 MB and grouping at least halves it; both formats give the same entries."""
-    rows, cols, ro, ci = synth.bernoulli(rows=1024, cols=4096, density=0.1, seed=4)
+    B gather would exceed ~400 MB and grouping cuts it 2.5x or more; both formats give the same entries."""
+    rows, cols, ro, ci = synth.bernoulli(rows=2048, cols=4096, density=0.1, seed=4)
     csr = engine.CSR.from_arrays(rows, cols, ro, ci)
     pipe = engine.Pipeline(csr, alpha=0.3, delta=0.0, device=0)
     st = pipe.plan_stats()
     assert st["group_size"] == 1 and st["grouped_group_size"] == 4
-    assert st["grouped_union_columns"] * 4 <= st["union_columns"] * 3
-    assert pipe.dense_choice(32)["group_size"] == 1       # 13 MB of gather
-    assert pipe.dense_choice(512)["group_size"] == 4      # 214 MB of gather
+    assert st["grouped_union_columns"] * 5 <= st["union_columns"] * 2
+    assert pipe.dense_choice(32)["group_size"] == 1       # 27 MB of gather
+    assert pipe.dense_choice(256)["group_size"] == 1      # 214 MB
+    assert pipe.dense_choice(512)["group_size"] == 4      # 428 MB
     for K in (32, 512):
         A = engine.make_data(rows * K, 5489)
         B = engine.make_data(cols * K, 5490)
