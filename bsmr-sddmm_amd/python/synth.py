@@ -128,6 +128,25 @@ def community_graph(n=4096, avg_degree=64, communities=8, inside=0.8, seed=3):
     return _rows_to_csr(n, n, per_row)
 
 
+def reddit_shard_like(rows=29121, cols=232965, avg_degree=492, communities=41, inside=0.8, first_row=0, seed=3):
+    """One row shard of a reddit-like graph (BASELINE configs[3]: 232 965^2, nnz 114.6 M, cut into 8 row ranges):
+    rows [first_row, first_row + rows) of a graph over `cols` vertices with power-law out-degrees (mean
+    `avg_degree`) and `communities` planted communities (contiguous id ranges; `inside` of a row's edges stay in
+    its own).  Vectorised: a row's duplicates are dropped, so nnz is a little below rows * avg_degree."""
+    rng = np.random.default_rng(seed)
+    deg = _fit_counts(rng.pareto(1.5, size=rows) + 0.2, rows * avg_degree, cols // 4)
+    size = -(-cols // communities)
+    per_row = []
+    for i in range(rows):
+        k = int(deg[i])
+        c0 = ((first_row + i) // size) * size
+        c1 = min(c0 + size, cols)
+        own = rng.random(k) < inside
+        c = np.where(own, rng.integers(c0, c1, size=k), rng.integers(0, cols, size=k))
+        per_row.append(np.unique(c))
+    return _rows_to_csr(rows, cols, per_row)
+
+
 def random_pattern(rows, cols, nnz, seed, empty_rows=0):
     """Small uniformly random pattern for unit tests (optionally with empty rows)."""
     rng = np.random.default_rng(seed)

@@ -612,3 +612,14 @@ def test_residue_blocks_are_promoted_to_dense_blocks(engine, oracle, monkeypatch
         want = run_hip(engine, plain, K, A, B, 2)
         same_path = flags == plain.dense_flags()
         assert np.array_equal(got[same_path], want[same_path])       # fp32 mode: untouched entries bit for bit
+
+
+def test_reddit_shard_scale(engine, oracle):
+    """BASELINE configs[3] at the size one of 8 GPUs sees: a 29 121 x 232 965 row shard of a reddit-like graph
+    (12.1 M stored entries, rows up to ~17 000 entries), K = 256, natural row order (the clustering of this shard
+    is timed by bench.py --workload reddit_shard_k256).  Every entry against the CPU loop and the path models."""
+    rows, cols, ro, ci = synth.reddit_shard_like()
+    assert ci.size > 12_000_000
+    pipe = check_case(engine, oracle, rows, cols, ro, ci, 256, 0.3, 0.3, 0, row_mode=engine.ROWS_IDENTITY)
+    st = pipe.plan_stats()
+    assert st["num_dense_entries"] + st["num_sparse_entries"] == ci.size

@@ -4,7 +4,7 @@
 TAG=${1:-r01}
 OUT=gpurun_out/results
 mkdir -p $OUT
-WLS=${WLS:-"nips_k32_hybrid nips_k128_dense nips_k512_dense cop20k_k128_hybrid dlmc_k512_dense dlmc_k512_d01 dlmc_k512_sparse mycielskian15_k32 mycielskian15_k128 mycielskian15_k256 mycielskian15_k512 mycielskian14_k32 mycielskian14_k128 mycielskian14_k256 mycielskian14_k512 trefethen20000_k32 trefethen20000_k128 trefethen20000_k256 trefethen20000_k512 wathen100_k32 wathen100_k128 wathen100_k256 wathen100_k512"}
+WLS=${WLS:-"nips_k32_hybrid nips_k128_dense nips_k512_dense cop20k_k128_hybrid dlmc_k512_dense dlmc_k512_d01 dlmc_k512_sparse reddit_shard_k256 mycielskian15_k32 mycielskian15_k128 mycielskian15_k256 mycielskian15_k512 mycielskian14_k32 mycielskian14_k128 mycielskian14_k256 mycielskian14_k512 trefethen20000_k32 trefethen20000_k128 trefethen20000_k256 trefethen20000_k512 wathen100_k32 wathen100_k128 wathen100_k256 wathen100_k512"}
 for wl in $WLS; do
   timeout -k 10 300 python3 bench.py --workload $wl --steps 200 --warmup 20 > $OUT/$wl.json 2> $OUT/$wl.err || echo "$wl failed"
   echo "$wl done"
