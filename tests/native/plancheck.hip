@@ -15,7 +15,8 @@ double nowUs() {
 }  // namespace
 
 // out[0] promoted (0/1), [1] promoted entries, [2] promoted blocks, [3] blocks after, [4] residue entries after,
-// [5] packPlan status, [6] packed dense entries, [7] packed residue entries, [8] promotion us, [9] packing us.
+// [5] packPlan status, [6] packed dense entries, [7] packed residue entries, [8] promotion us, [9] packing us,
+// [10] B columns gathered by the dense blocks ungrouped, [11] with 4 panels per group.
 // Returns 0, or the number of the first violated invariant.
 extern "C" int plancheck_promote(const bsmr_rphm_desc* in, uint32_t minAverage, uint64_t minEntries, uint64_t smallDense,
                                  uint32_t minColumnDegree, uint64_t* out) {
@@ -95,6 +96,8 @@ extern "C" int plancheck_promote(const bsmr_rphm_desc* in, uint32_t minAverage, 
     t0 = nowUs();
     out[5] = (uint64_t)(int64_t)bsmr::packPlan(d, opt, pk);
     out[9] = (uint64_t)(nowUs() - t0);
+    out[10] = bsmr::countUnionColumns(d, 1);
+    out[11] = bsmr::countUnionColumns(d, 4);
     out[6] = pk.numDenseEntries;
     out[7] = pk.numSparseEntries;
     return 0;
