@@ -163,7 +163,7 @@ int bsmr_plan_sparse_choice(const bsmr_plan *plan, uint32_t K, int compute_mode,
 
 /* Which kernel computes each stored entry: flags_host[i] (i = CSR index, nnz bytes, host memory) becomes 1
  * when the plan computes entry i on the dense (MFMA) path and 0 when the residue kernel does.  This is the
- * reference's dense / sparse split (BSMR::blockValues / sparseValues) after the plan's own moves
+ * reference's dense / sparse split (RPHM::blockValues_ / sparseValues_, reference src/BSMR.cpp:83-265) after the plan's own moves
  * (folded_dense_entries, promoted_sparse_entries); the accuracy contract of an entry follows its path. */
 int bsmr_plan_dense_flags(const bsmr_plan *plan, uint8_t *flags_host);
 
