@@ -30,6 +30,7 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -219,6 +220,15 @@ inline uint64_t countUnionColumns(const bsmr_rphm_desc* d, uint32_t h) {
 
 // Returns a bsmr_hip.h status.
 inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan& out) {
+    // BSMR_PACK_TIMING=1: phase times on stderr
+    const bool timing = std::getenv("BSMR_PACK_TIMING") != nullptr;
+    auto clock0 = std::chrono::steady_clock::now();
+    auto phase = [&](const char* name) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[packPlan] %-28s %8.1f ms\n", name, std::chrono::duration<double, std::milli>(now - clock0).count());
+        clock0 = now;
+    };
     const uint32_t P = d->num_row_panels;
     const uint64_t numRefBlocks = d->block_offsets[P];
     const uint64_t numSparse = d->sparse_value_offsets[P];
@@ -277,6 +287,7 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
     for (uint64_t i = 0; i < numRefBlocks * 16; ++i)
         if (d->dense_cols[i] > d->N) return BSMR_ERR_BAD_PLAN;
 
+    phase("rows + row bases");
     // ---- groups -------------------------------------------------------------
     const uint32_t H = opt.group == 2 || opt.group == 4 ? (uint32_t)opt.group : 1u;
     out.H = H;
@@ -334,6 +345,7 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
         }
     });
     { std::vector<std::vector<detail::ColumnUse>>().swap(groupCols); }
+    phase("blocks (columns, tiles)");
     out.numBlocks = out.blockMask.size();
     out.numTiles = 0;
     for (const uint8_t m : out.blockMask) out.numTiles += __builtin_popcount(m);
@@ -390,6 +402,7 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
             closeItem();
         }
     }
+    phase("items (window scan)");
     if (out.staged) {
         const size_t numItems = out.denseItems.size();
         out.rowBase.assign(numItems * R, 0);
@@ -441,6 +454,7 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
                         else out.tiles16[at] = (uint16_t)off;
                     }
     }
+    phase("destination encoding");
     if (opt.columnOrder) {
         // workgroup i of XCD x takes item x*(n/8)+i: an XCD then sees one column range of B.
         // The per-item arrays of the STAGED form are permuted along.
@@ -468,6 +482,7 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
         }
     }
 
+    phase("item order");
     // ---- sparse residue -------------------------------------------------------
     // Entries are independent, so inside a panel they may be visited in any order:
     // with columnOrder they are sorted by column id and the work items by their first
@@ -495,6 +510,7 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
         }
     }
     out.numSparseEntries = numSparse;
+    phase("residue entries");
     if (out.numDenseEntries + numSparse != d->nnz) return BSMR_ERR_BAD_PLAN;
 
     const uint32_t perWG = (uint32_t)std::max(32, opt.sparsePerItem);
