@@ -2,16 +2,16 @@
 // into extra 16x16 blocks of their panel.
 //
 // The reference cuts a panel's count-ordered columns into 16-column blocks and calls a block dense when it
-// holds more than ceil(delta * 256) entries (src/colReordering.cu / src/BSMR.cpp: the delta of the caller).
+// holds at least ceil(delta * 256) entries (reference src/colReordering.cu:244-271, the delta of the caller).
 // That cut-off balances the reference's two CUDA kernels.  On MI355X one dense block costs about as much as
-// 17-22 residue entries for every K (mycielskian15: K=32 0.195 ns / 11.1 ps, K=128 0.31 ns / 14.3 ps,
-// K=256 0.51 ns / 26 ps - a block gathers 16 columns of B, an entry one), blocks at the sparse end of a panel
-// ride in the dense kernel's tail almost for free, and a residue that disappears saves a launch and a kernel
-// boundary (3-5 us).  So a panel whose residue columns, cut into 16s, average at least `minAverage` (20)
-// entries per block gives ALL of its residue to the dense path; other panels keep theirs (mesh-like patterns,
-// ~19 per block over scattered columns, lose: cop20k-like K=128 43 -> 69 us when forced).  Measured with
-// everything promoted (alpha = delta = 0.3): mycielskian15 K=32 50.3 -> 26.2 us, K=128 66.8 -> 48.1,
-// K=512 188 -> 143; mycielskian14 K=128 33.6 -> 24.2; 4096^2 Bernoulli(0.1) K=512 delta=0.1 66.6 -> 43.5.
+// 11-27 residue entries (mycielskian15: K=32 0.12 ns / 11 ps, K=128 0.29 ns / 14 ps, K=512 0.91 ns / 40 ps -
+// a block gathers 16 columns of B, an entry one), blocks at the sparse end of a panel ride in the dense
+// kernel's tail almost for free, and a residue that disappears saves a launch and a kernel boundary (3-5 us).
+// So a panel whose residue columns, cut into 16s, average at least `minAverage` (20) entries per block gives
+// ALL of its residue to the dense path, and when the other panels would keep less than a quarter of all
+// entries they follow.  Measured (alpha = delta = 0.3, tools/promote_lab.py): mycielskian15 K=32 50.2 -> 26.3 us,
+// K=128 66.6 -> 47.5, K=512 184 -> 143; mycielskian14 K=128 34.2 -> 23.8; nips-like K=32 12.0 -> 8.7;
+// 4096^2 Bernoulli(0.1) K=512 delta=0.1 66.4 -> 43.1; reddit-like shard K=256: 6 of 9.5 M residue entries move.
 // The RPHM, its statistics and the reference-visible split stay as they are; only the device plan computes
 // those entries with the other kernel (same operands, same accuracy class as the low-precision residue).
 #pragma once
@@ -33,14 +33,15 @@ struct PromotedRphm {
 };
 
 // Returns true and fills `out` when blocks were promoted.  `minAverage`: entries per 16-column block that a
-// panel's residue needs on average; `minGain`: promoted entries below which a plan WITHOUT a dense part (fewer than `smallDense` dense entries: the plan folds those into the
-// residue) is left alone - a first dense block brings the conversion pass and a second launch with it.
+// panel's residue needs on average; `minEntries`: promoted entries below which a plan WITHOUT a dense part
+// (fewer than `smallDense` dense entries: the plan folds those into the residue) is left alone - a first dense
+// block brings the conversion pass and a second launch with it.
 // `minColumnDegree`: stored entries per column of S (nnz / N) the pattern needs at all - the dense kernel gathers 16
 // columns of B per block and is only cheap when those columns are reused from cache by other panels (graph / ML
 // patterns: mycielskian15 113, nips-like 60, Bernoulli 4096^2 410; mesh / FEM patterns: cop20k-like 11, wathen100 8,
 // Trefethen 14 - their blocks cost 0.58 ns instead of 0.29 and the conversion of A is paid on top).
 // Malformed input is left to packPlan's validation (returns false).
-inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, uint64_t minGain, uint64_t smallDense,
+inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, uint64_t minEntries, uint64_t smallDense,
                                 uint32_t minColumnDegree, PromotedRphm& out) {
     const uint32_t P = in.num_row_panels;
     const uint64_t numSparse = in.sparse_value_offsets[P];
@@ -118,7 +119,7 @@ inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, u
     for (uint32_t q = 0; q < P; ++q)
         if (qualifies[q]) qualified += in.sparse_value_offsets[q + 1] - in.sparse_value_offsets[q];
     const bool hasDense = oldBlocks != 0 && oldDense >= smallDense;
-    if ((hasDense || qualified >= minGain) && (numSparse - qualified) * 4 < in.nnz)
+    if ((hasDense || qualified >= minEntries) && (numSparse - qualified) * 4 < in.nnz)
         std::fill(qualifies.begin(), qualifies.end(), (uint8_t)1);
     uint64_t totalMoved = 0, totalNew = 0;
     for (uint32_t q = 0; q < P; ++q) {
@@ -129,7 +130,7 @@ inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, u
         totalNew += newBlocks[q];
         for (uint32_t i = in.sparse_value_offsets[q]; i < in.sparse_value_offsets[q + 1]; ++i) totalMoved += cell[i] != kNone;
     }
-    if (totalNew == 0 || (!hasDense && totalMoved < minGain)) return false;
+    if (totalNew == 0 || (!hasDense && totalMoved < minEntries)) return false;
     if (oldBlocks + totalNew > 0x00FFFFFFull) return false;
 
     // pass 2: the panel's blocks are its own followed by the promoted ones
