@@ -640,7 +640,7 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         for (uint32_t q = 0; q < P && offsetsOk; ++q)
             offsetsOk = d->block_offsets[q] <= d->block_offsets[q + 1] &&
                         d->sparse_value_offsets[q] <= d->sparse_value_offsets[q + 1];
-        // A panel whose residue averages >= 20 entries per 16-column block is cheaper on the MFMA path
+        // A panel whose residue averages >= 16 entries per 16-column block is cheaper on the MFMA path
         // (plan_promote.hpp; mycielskian15 alpha = delta = 0.3, K = 128: 66.8 -> 48.1 us).  A plan without a
         // dense part only changes when a million entries move: the first dense block brings the conversion pass
         // over A and a second launch with it (wathen100 K = 128, 227k entries forced over: 11.6 -> 19 us).
@@ -648,9 +648,10 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         uint64_t promotedEntries = 0;
         const uint64_t foldBelow = (uint64_t)std::max(0, envInt("BSMR_FOLD_DENSE_BELOW", 32768));
         if (offsetsOk && numSparse && (d->sparse_values && d->sparse_relative_rows && d->sparse_col_indices) &&
-            bsmr::promoteSparseBlocks(*d, (uint32_t)std::max(0, envInt("BSMR_PROMOTE_AVERAGE", 20)),
+            bsmr::promoteSparseBlocks(*d, (uint32_t)std::max(0, envInt("BSMR_PROMOTE_AVERAGE", 16)),
                                       (uint64_t)envInt("BSMR_PROMOTE_MIN_ENTRIES_K", 1000) * 1000ull, foldBelow,
-                                      (uint32_t)std::max(0, envInt("BSMR_PROMOTE_COLUMN_DEGREE", 32)), promoted)) {
+                                      (uint32_t)std::max(0, envInt("BSMR_PROMOTE_COLUMN_DEGREE", 32)),
+                                      (uint32_t)std::max(0, envInt("BSMR_PROMOTE_HEAD", 0)), promoted)) {
             // (a dense part that would still be folded below stays as the RPHM has it)
             if (d->nnz - promoted.desc.sparse_value_offsets[P] >= foldBelow) {
                 d = &promoted.desc;

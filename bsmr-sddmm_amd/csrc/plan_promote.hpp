@@ -7,11 +7,12 @@
 // 11-27 residue entries (mycielskian15: K=32 0.12 ns / 11 ps, K=128 0.29 ns / 14 ps, K=512 0.91 ns / 40 ps -
 // a block gathers 16 columns of B, an entry one), blocks at the sparse end of a panel ride in the dense
 // kernel's tail almost for free, and a residue that disappears saves a launch and a kernel boundary (3-5 us).
-// So a panel whose residue columns, cut into 16s, average at least `minAverage` (20) entries per block gives
+// So a panel whose residue columns, cut into 16s, average at least `minAverage` (16) entries per block gives
 // ALL of its residue to the dense path, and when the other panels would keep less than a quarter of all
 // entries they follow.  Measured (alpha = delta = 0.3, tools/promote_lab.py): mycielskian15 K=32 50.2 -> 26.3 us,
 // K=128 66.6 -> 47.5, K=512 184 -> 143; mycielskian14 K=128 34.2 -> 23.8; nips-like K=32 12.0 -> 8.7;
-// 4096^2 Bernoulli(0.1) K=512 delta=0.1 66.4 -> 43.1; reddit-like shard K=256: 6 of 9.5 M residue entries move.
+// 4096^2 Bernoulli(0.1) K=512 delta=0.1 66.4 -> 43.1; reddit-like shard K=256 (residue 9.5 M entries): nothing
+// moved 0.60 ms, panels averaging >= 20 only 0.434 ms, all of it 0.403 ms.
 // The RPHM, its statistics and the reference-visible split stay as they are; only the device plan computes
 // those entries with the other kernel (same operands, same accuracy class as the low-precision residue).
 #pragma once
@@ -40,9 +41,11 @@ struct PromotedRphm {
 // columns of B per block and is only cheap when those columns are reused from cache by other panels (graph / ML
 // patterns: mycielskian15 113, nips-like 60, Bernoulli 4096^2 410; mesh / FEM patterns: cop20k-like 11, wathen100 8,
 // Trefethen 14 - their blocks cost 0.58 ns instead of 0.29 and the conversion of A is paid on top).
+// `headMin`: a panel that does not qualify as a whole still gives its leading blocks with at least this many entries
+// (0 = none; reddit-like shard K=256: a block costs 0.71 ns, a residue entry 44 ps).
 // Malformed input is left to packPlan's validation (returns false).
 inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, uint64_t minEntries, uint64_t smallDense,
-                                uint32_t minColumnDegree, PromotedRphm& out) {
+                                uint32_t minColumnDegree, uint32_t headMin, PromotedRphm& out) {
     const uint32_t P = in.num_row_panels;
     const uint64_t numSparse = in.sparse_value_offsets[P];
     if (minAverage == 0 || numSparse == 0 || numSparse > 0xFFFFFFF0ull) return false;
@@ -56,6 +59,7 @@ inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, u
     std::vector<std::vector<uint32_t>> newCols((size_t)P);
     const unsigned workers = packThreads();
     std::vector<uint8_t> bad(workers, 0), qualifies((size_t)P, 0);
+    std::vector<uint32_t> headBlocks((size_t)P, 0), take((size_t)P, 0);
     parallelChunks(P, 16, [&](size_t q0, size_t q1, size_t w) {
         struct Column {
             uint32_t col, count, first;
@@ -90,9 +94,14 @@ inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, u
                              [](const Column& x, const Column& y) { return x.count > y.count; });
             const uint64_t blocksNeeded = (columns.size() + 15) / 16;
             qualifies[q] = (uint64_t)(s1 - s0) >= (uint64_t)minAverage * blocksNeeded;
+            bool head = headMin != 0;
             for (size_t c0 = 0; c0 < columns.size(); c0 += 16) {
                 const size_t c1 = std::min(columns.size(), c0 + 16);
                 const uint32_t block = newBlocks[q]++;
+                uint32_t inBlock = 0;
+                for (size_t c = c0; c < c1; ++c) inBlock += columns[c].count;
+                head = head && inBlock >= headMin;
+                if (head) headBlocks[q] = block + 1;
                 taken.assign(256, 0);
                 for (size_t c = c0; c < c1; ++c) {
                     newCols[q].push_back(columns[c].col);
@@ -119,16 +128,14 @@ inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, u
     for (uint32_t q = 0; q < P; ++q)
         if (qualifies[q]) qualified += in.sparse_value_offsets[q + 1] - in.sparse_value_offsets[q];
     const bool hasDense = oldBlocks != 0 && oldDense >= smallDense;
-    if ((hasDense || qualified >= minEntries) && (numSparse - qualified) * 4 < in.nnz)
-        std::fill(qualifies.begin(), qualifies.end(), (uint8_t)1);
+    const bool everything = (hasDense || qualified >= minEntries) && (numSparse - qualified) * 4 < in.nnz;
     uint64_t totalMoved = 0, totalNew = 0;
     for (uint32_t q = 0; q < P; ++q) {
-        if (!qualifies[q]) {
-            newBlocks[q] = 0;
-            continue;
-        }
-        totalNew += newBlocks[q];
-        for (uint32_t i = in.sparse_value_offsets[q]; i < in.sparse_value_offsets[q + 1]; ++i) totalMoved += cell[i] != kNone;
+        take[q] = everything || qualifies[q] ? newBlocks[q] : headBlocks[q];
+        totalNew += take[q];
+        if (take[q])
+            for (uint32_t i = in.sparse_value_offsets[q]; i < in.sparse_value_offsets[q + 1]; ++i)
+                totalMoved += cell[i] != kNone && cell[i] / 256 < take[q];
     }
     if (totalNew == 0 || (!hasDense && totalMoved < minEntries)) return false;
     if (oldBlocks + totalNew > 0x00FFFFFFull) return false;
@@ -137,10 +144,10 @@ inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, u
     out.blockOffsets.assign((size_t)P + 1, 0);
     out.sparseOffsets.assign((size_t)P + 1, 0);
     for (uint32_t q = 0; q < P; ++q) {
-        out.blockOffsets[q + 1] = out.blockOffsets[q] + (in.block_offsets[q + 1] - in.block_offsets[q]) + newBlocks[q];
+        out.blockOffsets[q + 1] = out.blockOffsets[q] + (in.block_offsets[q + 1] - in.block_offsets[q]) + take[q];
         uint32_t kept = 0;
         for (uint32_t i = in.sparse_value_offsets[q]; i < in.sparse_value_offsets[q + 1]; ++i)
-            kept += !qualifies[q] || cell[i] == kNone;
+            kept += cell[i] == kNone || cell[i] / 256 >= take[q];
         out.sparseOffsets[q + 1] = out.sparseOffsets[q] + kept;
     }
     const uint64_t blocks = out.blockOffsets[P];
@@ -159,10 +166,10 @@ inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, u
                 std::copy(in.block_values + (uint64_t)in.block_offsets[q] * 256,
                           in.block_values + (uint64_t)in.block_offsets[q + 1] * 256, out.blockValues.begin() + b0 * 256);
             }
-            if (qualifies[q]) std::copy(newCols[q].begin(), newCols[q].end(), out.denseCols.begin() + (b0 + own) * 16);
+            std::copy(newCols[q].begin(), newCols[q].begin() + (size_t)take[q] * 16, out.denseCols.begin() + (b0 + own) * 16);
             uint32_t at = out.sparseOffsets[q];
             for (uint32_t i = in.sparse_value_offsets[q]; i < in.sparse_value_offsets[q + 1]; ++i) {
-                if (!qualifies[q] || cell[i] == kNone) {
+                if (cell[i] == kNone || cell[i] / 256 >= take[q]) {
                     out.sparseValues[at] = in.sparse_values[i];
                     out.sparseRows[at] = in.sparse_relative_rows[i];
                     out.sparseCols[at] = in.sparse_col_indices[i];

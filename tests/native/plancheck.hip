@@ -19,12 +19,12 @@ double nowUs() {
 // [10] B columns gathered by the dense blocks ungrouped, [11] with 4 panels per group.
 // Returns 0, or the number of the first violated invariant.
 extern "C" int plancheck_promote(const bsmr_rphm_desc* in, uint32_t minAverage, uint64_t minEntries, uint64_t smallDense,
-                                 uint32_t minColumnDegree, uint64_t* out) {
+                                 uint32_t minColumnDegree, uint32_t headMin, uint64_t* out) {
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     const uint32_t P = in->num_row_panels;
     bsmr::PromotedRphm pr;
     double t0 = nowUs();
-    const bool did = bsmr::promoteSparseBlocks(*in, minAverage, minEntries, smallDense, minColumnDegree, pr);
+    const bool did = bsmr::promoteSparseBlocks(*in, minAverage, minEntries, smallDense, minColumnDegree, headMin, pr);
     out[8] = (uint64_t)(nowUs() - t0);
     const bsmr_rphm_desc* d = did ? &pr.desc : in;
     out[0] = did;

@@ -16,9 +16,9 @@ REPO = Path(__file__).resolve().parent.parent
 def plancheck(engine):
     lib = C.CDLL(str(REPO / "tests" / "native" / "libplancheck.so"))
     lib.plancheck_promote.restype = C.c_int
-    lib.plancheck_promote.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+    lib.plancheck_promote.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
 
-    def run(rows, cols, ro, ci, alpha, delta, min_average=20, min_entries=1_000_000, small_dense=32768, column_degree=32):
+    def run(rows, cols, ro, ci, alpha, delta, min_average=16, min_entries=1_000_000, small_dense=32768, column_degree=32, head=0):
         csr = engine.CSR.from_arrays(rows, cols, ro, ci)
         pipe = engine.Pipeline(csr, alpha=alpha, delta=delta, device=-1)
         arrays = pipe.arrays()
@@ -35,7 +35,7 @@ def plancheck(engine):
         d.sparse_value_offsets, d.sparse_values = cast(keep["sparseValueOffsets"]), cast(keep["sparseValues"])
         d.sparse_relative_rows, d.sparse_col_indices = cast(keep["sparseRelativeRows"]), cast(keep["sparseColIndices"])
         out = (C.c_uint64 * 12)()
-        rc = lib.plancheck_promote(C.byref(d), min_average, min_entries, small_dense, column_degree, out)
+        rc = lib.plancheck_promote(C.byref(d), min_average, min_entries, small_dense, column_degree, head, out)
         names = ("promoted", "promoted_entries", "promoted_blocks", "blocks", "residue", "pack_status", "packed_dense",
                  "packed_residue", "promote_us", "pack_us", "union_columns", "union_columns_grouped4")
         res = dict(zip(names, (int(v) for v in out)))
@@ -46,12 +46,12 @@ def plancheck(engine):
     return run
 
 
-@pytest.mark.parametrize("min_average", [1, 8, 20, 40])
+@pytest.mark.parametrize("min_average,head", [(1, 0), (8, 0), (20, 0), (40, 0), (40, 12), (200, 6)])
 @pytest.mark.parametrize("delta", [0.05, 0.3, 1.1])
-def test_promotion_keeps_every_entry_exactly_once(plancheck, min_average, delta):
+def test_promotion_keeps_every_entry_exactly_once(plancheck, min_average, head, delta):
     rows, cols, ro, ci = synth.community_graph(n=900, avg_degree=70, communities=6, seed=5)
     rc, r = plancheck(rows, cols, ro, ci, 0.2, delta, min_average=min_average, min_entries=1000, small_dense=100,
-                      column_degree=0)
+                      column_degree=0, head=head)
     assert rc == 0, f"invariant {rc} violated: {r}"
     assert r["pack_status"] == 0
     assert r["packed_dense"] + r["packed_residue"] == r["nnz"]
@@ -80,7 +80,7 @@ def test_promotion_rules(plancheck):
     rc, r = plancheck(rows, cols, ro, ci, 0.3, 0.3, min_entries=1000)
     assert rc == 0 and r["promoted"] == 0
     rc, r = plancheck(rows, cols, ro, ci, 0.3, 0.3, min_entries=1000, column_degree=0)
-    assert rc == 0 and r["promoted"] == 1                        # (their panels do fill 20 per block)
+    assert rc == 0 and r["promoted"] == 1                        # (their panels do fill 16 per block)
 
 
 def test_promotion_with_repeated_entries(plancheck):

@@ -18,7 +18,9 @@ from bench import WORKLOADS  # noqa: E402
 
 args = sys.argv[1:]
 levels = ["0", "16", "20", "24"]
-if args and args[0] == "--from":
+knob = "BSMR_PROMOTE_AVERAGE"
+if args and args[0] in ("--from", "--head"):   # --head: leading blocks of panels that do not qualify (BSMR_PROMOTE_HEAD)
+    knob = "BSMR_PROMOTE_AVERAGE" if args[0] == "--from" else "BSMR_PROMOTE_HEAD"
     levels = args[1].split(",")
     args = args[2:]
 names = args or ["mycielskian15_k128", "mycielskian15_k32", "mycielskian14_k128", "nips_k32_hybrid", "dlmc_k512_d01",
@@ -34,7 +36,7 @@ for name in names:
     B = torch.from_numpy(eng.make_data(cols * K, 5490)).to(dev)
     P = torch.zeros(csr.nnz, dtype=torch.float32, device=dev)
     for level in levels:
-        os.environ["BSMR_PROMOTE_AVERAGE"] = level
+        os.environ[knob] = level
         st, plan = eng.plan_from_arrays(rows, cols, csr.nnz, arrays, device=0)
         assert st == 0, st
         raw = eng.PlanStats()
@@ -43,7 +45,7 @@ for name in names:
         best = min((eng.sddmm_timed(plan, K, A.data_ptr(), B.data_ptr(), P.data_ptr(), 0, s, warmup=5, iters=100)
                     for _ in range(3)), key=lambda t: t["total_ms"])
         eng.plan_destroy(plan)
-        print(json.dumps({"workload": name, "from": int(level), "promoted": stats["promoted_sparse_entries"],
+        print(json.dumps({"workload": name, knob: int(level), "promoted": stats["promoted_sparse_entries"],
                           "dense_blocks": stats["num_dense_blocks"], "dense": stats["num_dense_entries"],
                           "sparse": stats["num_sparse_entries"], **{k: round(v * 1e3, 2) for k, v in best.items()}}),
               flush=True)
