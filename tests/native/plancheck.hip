@@ -16,7 +16,8 @@ double nowUs() {
 
 // out[0] promoted (0/1), [1] promoted entries, [2] promoted blocks, [3] blocks after, [4] residue entries after,
 // [5] packPlan status, [6] packed dense entries, [7] packed residue entries, [8] promotion us, [9] packing us,
-// [10] B columns gathered by the dense blocks ungrouped, [11] with 4 panels per group.
+// [10] B columns gathered by the dense blocks ungrouped, [11] with 4 panels per group,
+// [12] bytes per index-tile element (1 = windowed 8-bit, 2 / 4 = offsets from the row's first dense entry).
 // Returns 0, or the number of the first violated invariant.
 extern "C" int plancheck_promote(const bsmr_rphm_desc* in, uint32_t minAverage, uint64_t minEntries, uint64_t smallDense,
                                  uint32_t minColumnDegree, uint32_t headMin, uint64_t* out) {
@@ -98,6 +99,7 @@ extern "C" int plancheck_promote(const bsmr_rphm_desc* in, uint32_t minAverage, 
     out[9] = (uint64_t)(nowUs() - t0);
     out[10] = bsmr::countUnionColumns(d, 1);
     out[11] = bsmr::countUnionColumns(d, 4);
+    out[12] = !pk.tiles8.empty() ? 1 : !pk.tiles16.empty() ? 2 : !pk.tiles32.empty() ? 4 : 0;
     out[6] = pk.numDenseEntries;
     out[7] = pk.numSparseEntries;
     return 0;

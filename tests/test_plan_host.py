@@ -34,10 +34,10 @@ def plancheck(engine):
         d.block_offsets, d.block_values = cast(keep["blockOffsets"]), cast(keep["blockValues"])
         d.sparse_value_offsets, d.sparse_values = cast(keep["sparseValueOffsets"]), cast(keep["sparseValues"])
         d.sparse_relative_rows, d.sparse_col_indices = cast(keep["sparseRelativeRows"]), cast(keep["sparseColIndices"])
-        out = (C.c_uint64 * 12)()
+        out = (C.c_uint64 * 13)()
         rc = lib.plancheck_promote(C.byref(d), min_average, min_entries, small_dense, column_degree, head, out)
         names = ("promoted", "promoted_entries", "promoted_blocks", "blocks", "residue", "pack_status", "packed_dense",
-                 "packed_residue", "promote_us", "pack_us", "union_columns", "union_columns_grouped4")
+                 "packed_residue", "promote_us", "pack_us", "union_columns", "union_columns_grouped4", "tile_bytes")
         res = dict(zip(names, (int(v) for v in out)))
         res["rphm_dense"] = int(csr.nnz - keep["sparseValues"].size)
         res["rphm_blocks"] = int(keep["blockOffsets"][-1])
