@@ -191,5 +191,6 @@ def run_sharded(eng, torch, dist, dev, rank, world, make_pattern, K, alpha, delt
         "plan_build_s": round(plan_s, 3),
         # this rank's shard, for the caller's roofline (used on rank 0)
         "rank0": {"kernels_ms": kt, "pattern": (lrows, cols, lro, lci), "dense_tiles": pipe.dense_choice(K)["tiles"],
+                  "union_columns": pipe.dense_choice(K)["union_columns"], "sparse_nnz": pipe.plan_stats()["num_sparse_entries"],
                   "sparse_lowp": bool(pipe.sparse_choice(K, mode)["low_precision"])},
     }
