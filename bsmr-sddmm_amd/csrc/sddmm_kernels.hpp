@@ -729,6 +729,72 @@ sparseEntries(const float* __restrict__ A, const float* __restrict__ B, uint32_t
     const uint32_t chunks = K >> 2;  // float4 chunks per row
     const uint32_t ldsStride = K + kSparseLdsPad;
 
+    constexpr uint32_t groups = kThreads / LPE;
+    const uint32_t group = threadIdx.x / LPE;
+    const uint32_t t = threadIdx.x % LPE;
+    // every group runs the same number of rounds so that all lanes of a wave
+    // reach the shuffles together
+    const uint32_t rounds = (item.count + groups - 1) / groups;
+
+    // Tuned shapes over a staged panel: the chain item -> panel rows -> A rows -> barrier -> (entry -> B column)
+    // per round is what a workgroup's time consists of, so the entries of two rounds and the B chunks of the
+    // next round are requested ahead: round 0's before the panel is staged, round r+1's before round r is summed.
+    // Same per-lane arithmetic in the same order as the plain loop below.
+    // (CPL <= 4 only: with 8 chunks per lane the second buffer costs occupancy - Trefethen_20000 K=256 25.4 -> 29.5 us)
+    if constexpr (CPL > 0 && CPL <= 4 && A_IN_LDS && !FREE) {
+        auto entryOf = [&](uint32_t round, uint32_t& idx, uint32_t& col, uint32_t& row) {
+            const uint32_t e = round * groups + group;
+            idx = item.start + (e < item.count ? e : 0u);
+            col = entryCol[idx];
+            row = entryRow[idx];
+        };
+        auto request = [&](f32x4 (&bv)[CPL], uint32_t col) {
+            const float* bCol = B + (size_t)col * K;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) bv[c] = *reinterpret_cast<const f32x4*>(bCol + (t + c * LPE) * 4u);
+        };
+        auto finish = [&](const f32x4 (&bv)[CPL], uint32_t round, uint32_t idx, uint32_t row) {
+            const float* aRow = panelA + row * ldsStride;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(aRow + (t + c * LPE) * 4u);
+                acc = __builtin_fmaf(av[0], bv[c][0], acc);
+                acc = __builtin_fmaf(av[1], bv[c][1], acc);
+                acc = __builtin_fmaf(av[2], bv[c][2], acc);
+                acc = __builtin_fmaf(av[3], bv[c][3], acc);
+            }
+#pragma unroll
+            for (int off = LPE / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, LPE);
+            if (round * groups + group < item.count && t == 0) P[entryDst[idx]] = acc;
+        };
+        uint32_t idx0, col0, row0, idx1, col1, row1;
+        entryOf(0, idx0, col0, row0);
+        entryOf(1, idx1, col1, row1);
+        f32x4 bvA[CPL], bvB[CPL];
+        request(bvA, col0);
+        for (uint32_t i = threadIdx.x; i < 16u * chunks; i += kThreads) {
+            const uint32_t row = i / chunks, q = i - row * chunks;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(
+                A + (size_t)panelRows[item.panel * 16u + row] * K + q * 4u);
+            *reinterpret_cast<f32x4*>(panelA + row * ldsStride + q * 4u) = v;
+        }
+        __syncthreads();
+        for (uint32_t round = 0; round < rounds; round += 2) {
+            uint32_t idx2 = 0, col2 = 0, row2 = 0, idx3 = 0, col3 = 0, row3 = 0;
+            if (round + 1 < rounds) request(bvB, col1);
+            if (round + 2 < rounds) entryOf(round + 2, idx2, col2, row2);
+            finish(bvA, round, idx0, row0);
+            if (round + 1 >= rounds) break;
+            if (round + 2 < rounds) request(bvA, col2);
+            if (round + 3 < rounds) entryOf(round + 3, idx3, col3, row3);
+            finish(bvB, round + 1, idx1, row1);
+            idx0 = idx2; col0 = col2; row0 = row2;
+            idx1 = idx3; col1 = col3; row1 = row3;
+        }
+        return;
+    }
+
     if constexpr (A_IN_LDS) {
         for (uint32_t i = threadIdx.x; i < 16u * chunks; i += kThreads) {
             const uint32_t row = i / chunks, q = i - row * chunks;
@@ -738,13 +804,6 @@ sparseEntries(const float* __restrict__ A, const float* __restrict__ B, uint32_t
         }
         __syncthreads();
     }
-
-    constexpr uint32_t groups = kThreads / LPE;
-    const uint32_t group = threadIdx.x / LPE;
-    const uint32_t t = threadIdx.x % LPE;
-    // every group runs the same number of rounds so that all lanes of a wave
-    // reach the shuffles together
-    const uint32_t rounds = (item.count + groups - 1) / groups;
     for (uint32_t round = 0; round < rounds; ++round) {
         const uint32_t e = round * groups + group;
         const bool live = e < item.count;
@@ -820,6 +879,29 @@ sparseEntriesLowp(const uint16_t* __restrict__ A16, const uint16_t* __restrict__
     const SparseItem item = items[xcdContiguous(blockIdx.x, gridDim.x)];
     const uint32_t chunks = K >> 3;  // 16-byte chunks (8 elements) per row
     const uint32_t ldsStride = 2u * K + kSparseLdsPad16;
+    constexpr uint32_t groups = kThreads / LPE;
+    const uint32_t group = threadIdx.x / LPE;
+    const uint32_t t = threadIdx.x % LPE;
+    const uint32_t rounds = (item.count + groups - 1) / groups;
+    constexpr bool PIPELINED = CPL > 0 && CPL <= 4 && A_IN_LDS && !FREE;
+    auto entryOf = [&](uint32_t round, uint32_t& idx, uint32_t& col, uint32_t& row) {
+        const uint32_t e = round * groups + group;
+        idx = item.start + (e < item.count ? e : 0u);
+        col = entryCol[idx];
+        row = entryRow[idx];
+    };
+    auto request = [&](u32x4 (&bv)[CPL > 0 ? CPL : 1], uint32_t col) {
+        const uint16_t* bCol = B16 + (size_t)col * K;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) bv[c] = *reinterpret_cast<const u32x4*>(bCol + (t + c * LPE) * 8u);
+    };
+    uint32_t idx0 = 0, col0 = 0, row0 = 0, idx1 = 0, col1 = 0, row1 = 0;
+    u32x4 bvA[CPL > 0 ? CPL : 1], bvB[CPL > 0 ? CPL : 1];
+    if constexpr (PIPELINED) {  // round 0's entry and B chunks are on their way while the panel is staged
+        entryOf(0, idx0, col0, row0);
+        entryOf(1, idx1, col1, row1);
+        request(bvA, col0);
+    }
 
     if constexpr (A_IN_LDS) {
         static_assert(!A_FP32 || !FREE, "fp32 A is rounded while a panel is staged");
@@ -849,10 +931,37 @@ sparseEntriesLowp(const uint16_t* __restrict__ A16, const uint16_t* __restrict__
         __syncthreads();
     }
 
-    constexpr uint32_t groups = kThreads / LPE;
-    const uint32_t group = threadIdx.x / LPE;
-    const uint32_t t = threadIdx.x % LPE;
-    const uint32_t rounds = (item.count + groups - 1) / groups;
+    if constexpr (PIPELINED) {  // see sparseEntries: entries two rounds ahead, B chunks one round ahead
+        auto finish = [&](const u32x4 (&bv)[CPL > 0 ? CPL : 1], uint32_t round, uint32_t idx, uint32_t row) {
+            const uint8_t* aRow = panelA16 + row * ldsStride;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const u32x4 av = *reinterpret_cast<const u32x4*>(aRow + (t + c * LPE) * 16u);
+                acc = dot2<MODE>(av[0], bv[c][0], acc);
+                acc = dot2<MODE>(av[1], bv[c][1], acc);
+                acc = dot2<MODE>(av[2], bv[c][2], acc);
+                acc = dot2<MODE>(av[3], bv[c][3], acc);
+            }
+#pragma unroll
+            for (int off = LPE / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, LPE);
+            if (round * groups + group < item.count && t == 0) P[entryDst[idx]] = acc;
+        };
+        for (uint32_t round = 0; round < rounds; round += 2) {
+            uint32_t idx2 = 0, col2 = 0, row2 = 0, idx3 = 0, col3 = 0, row3 = 0;
+            if (round + 1 < rounds) request(bvB, col1);
+            if (round + 2 < rounds) entryOf(round + 2, idx2, col2, row2);
+            finish(bvA, round, idx0, row0);
+            if (round + 1 >= rounds) break;
+            if (round + 2 < rounds) request(bvA, col2);
+            if (round + 3 < rounds) entryOf(round + 3, idx3, col3, row3);
+            finish(bvB, round + 1, idx1, row1);
+            idx0 = idx2; col0 = col2; row0 = row2;
+            idx1 = idx3; col1 = col3; row1 = row3;
+        }
+        return;
+    }
+
     for (uint32_t round = 0; round < rounds; ++round) {
         const uint32_t e = round * groups + group;
         const bool live = e < item.count;
