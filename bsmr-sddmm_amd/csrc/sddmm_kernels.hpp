@@ -740,8 +740,10 @@ sparseEntries(const float* __restrict__ A, const float* __restrict__ B, uint32_t
     // per round is what a workgroup's time consists of, so the entries of two rounds and the B chunks of the
     // next round are requested ahead: round 0's before the panel is staged, round r+1's before round r is summed.
     // Same per-lane arithmetic in the same order as the plain loop below.
-    // (CPL <= 4 only: with 8 chunks per lane the second buffer costs occupancy - Trefethen_20000 K=256 25.4 -> 29.5 us)
-    if constexpr (CPL > 0 && CPL <= 4 && A_IN_LDS && !FREE) {
+    // (with 8 chunks per lane a second B buffer costs occupancy - Trefethen_20000 K=256 25.4 -> 29.5 us - so those
+    // shapes only keep the entries ahead and request round r+1's chunks right after round r is summed)
+    if constexpr (CPL > 0 && A_IN_LDS && !FREE) {
+        constexpr bool TWO_BUFFERS = CPL <= 4;
         auto entryOf = [&](uint32_t round, uint32_t& idx, uint32_t& col, uint32_t& row) {
             const uint32_t e = round * groups + group;
             idx = item.start + (e < item.count ? e : 0u);
@@ -771,7 +773,7 @@ sparseEntries(const float* __restrict__ A, const float* __restrict__ B, uint32_t
         uint32_t idx0, col0, row0, idx1, col1, row1;
         entryOf(0, idx0, col0, row0);
         entryOf(1, idx1, col1, row1);
-        f32x4 bvA[CPL], bvB[CPL];
+        f32x4 bvA[CPL], bvB[TWO_BUFFERS ? CPL : 1];
         request(bvA, col0);
         for (uint32_t i = threadIdx.x; i < 16u * chunks; i += kThreads) {
             const uint32_t row = i / chunks, q = i - row * chunks;
@@ -780,17 +782,28 @@ sparseEntries(const float* __restrict__ A, const float* __restrict__ B, uint32_t
             *reinterpret_cast<f32x4*>(panelA + row * ldsStride + q * 4u) = v;
         }
         __syncthreads();
-        for (uint32_t round = 0; round < rounds; round += 2) {
-            uint32_t idx2 = 0, col2 = 0, row2 = 0, idx3 = 0, col3 = 0, row3 = 0;
-            if (round + 1 < rounds) request(bvB, col1);
-            if (round + 2 < rounds) entryOf(round + 2, idx2, col2, row2);
-            finish(bvA, round, idx0, row0);
-            if (round + 1 >= rounds) break;
-            if (round + 2 < rounds) request(bvA, col2);
-            if (round + 3 < rounds) entryOf(round + 3, idx3, col3, row3);
-            finish(bvB, round + 1, idx1, row1);
-            idx0 = idx2; col0 = col2; row0 = row2;
-            idx1 = idx3; col1 = col3; row1 = row3;
+        if constexpr (TWO_BUFFERS) {
+            for (uint32_t round = 0; round < rounds; round += 2) {
+                uint32_t idx2 = 0, col2 = 0, row2 = 0, idx3 = 0, col3 = 0, row3 = 0;
+                if (round + 1 < rounds) request(bvB, col1);
+                if (round + 2 < rounds) entryOf(round + 2, idx2, col2, row2);
+                finish(bvA, round, idx0, row0);
+                if (round + 1 >= rounds) break;
+                if (round + 2 < rounds) request(bvA, col2);
+                if (round + 3 < rounds) entryOf(round + 3, idx3, col3, row3);
+                finish(bvB, round + 1, idx1, row1);
+                idx0 = idx2; col0 = col2; row0 = row2;
+                idx1 = idx3; col1 = col3; row1 = row3;
+            }
+        } else {
+            for (uint32_t round = 0; round < rounds; ++round) {
+                uint32_t idx2 = 0, col2 = 0, row2 = 0;
+                if (round + 2 < rounds) entryOf(round + 2, idx2, col2, row2);
+                finish(bvA, round, idx0, row0);
+                if (round + 1 < rounds) request(bvA, col1);
+                idx0 = idx1; col0 = col1; row0 = row1;
+                idx1 = idx2; col1 = col2; row1 = row2;
+            }
         }
         return;
     }
@@ -883,7 +896,8 @@ sparseEntriesLowp(const uint16_t* __restrict__ A16, const uint16_t* __restrict__
     const uint32_t group = threadIdx.x / LPE;
     const uint32_t t = threadIdx.x % LPE;
     const uint32_t rounds = (item.count + groups - 1) / groups;
-    constexpr bool PIPELINED = CPL > 0 && CPL <= 4 && A_IN_LDS && !FREE;
+    constexpr bool PIPELINED = CPL > 0 && A_IN_LDS && !FREE;
+    constexpr bool TWO_BUFFERS = CPL <= 4;
     auto entryOf = [&](uint32_t round, uint32_t& idx, uint32_t& col, uint32_t& row) {
         const uint32_t e = round * groups + group;
         idx = item.start + (e < item.count ? e : 0u);
@@ -896,7 +910,7 @@ sparseEntriesLowp(const uint16_t* __restrict__ A16, const uint16_t* __restrict__
         for (int c = 0; c < CPL; ++c) bv[c] = *reinterpret_cast<const u32x4*>(bCol + (t + c * LPE) * 8u);
     };
     uint32_t idx0 = 0, col0 = 0, row0 = 0, idx1 = 0, col1 = 0, row1 = 0;
-    u32x4 bvA[CPL > 0 ? CPL : 1], bvB[CPL > 0 ? CPL : 1];
+    u32x4 bvA[CPL > 0 ? CPL : 1], bvB[CPL > 0 && TWO_BUFFERS ? CPL : 1];
     if constexpr (PIPELINED) {  // round 0's entry and B chunks are on their way while the panel is staged
         entryOf(0, idx0, col0, row0);
         entryOf(1, idx1, col1, row1);
@@ -947,17 +961,28 @@ sparseEntriesLowp(const uint16_t* __restrict__ A16, const uint16_t* __restrict__
             for (int off = LPE / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, LPE);
             if (round * groups + group < item.count && t == 0) P[entryDst[idx]] = acc;
         };
-        for (uint32_t round = 0; round < rounds; round += 2) {
-            uint32_t idx2 = 0, col2 = 0, row2 = 0, idx3 = 0, col3 = 0, row3 = 0;
-            if (round + 1 < rounds) request(bvB, col1);
-            if (round + 2 < rounds) entryOf(round + 2, idx2, col2, row2);
-            finish(bvA, round, idx0, row0);
-            if (round + 1 >= rounds) break;
-            if (round + 2 < rounds) request(bvA, col2);
-            if (round + 3 < rounds) entryOf(round + 3, idx3, col3, row3);
-            finish(bvB, round + 1, idx1, row1);
-            idx0 = idx2; col0 = col2; row0 = row2;
-            idx1 = idx3; col1 = col3; row1 = row3;
+        if constexpr (TWO_BUFFERS) {
+            for (uint32_t round = 0; round < rounds; round += 2) {
+                uint32_t idx2 = 0, col2 = 0, row2 = 0, idx3 = 0, col3 = 0, row3 = 0;
+                if (round + 1 < rounds) request(bvB, col1);
+                if (round + 2 < rounds) entryOf(round + 2, idx2, col2, row2);
+                finish(bvA, round, idx0, row0);
+                if (round + 1 >= rounds) break;
+                if (round + 2 < rounds) request(bvA, col2);
+                if (round + 3 < rounds) entryOf(round + 3, idx3, col3, row3);
+                finish(bvB, round + 1, idx1, row1);
+                idx0 = idx2; col0 = col2; row0 = row2;
+                idx1 = idx3; col1 = col3; row1 = row3;
+            }
+        } else {
+            for (uint32_t round = 0; round < rounds; ++round) {
+                uint32_t idx2 = 0, col2 = 0, row2 = 0;
+                if (round + 2 < rounds) entryOf(round + 2, idx2, col2, row2);
+                finish(bvA, round, idx0, row0);
+                if (round + 1 < rounds) request(bvA, col1);
+                idx0 = idx1; col0 = col1; row0 = row1;
+                idx1 = idx2; col1 = col2; row1 = row2;
+            }
         }
         return;
     }
