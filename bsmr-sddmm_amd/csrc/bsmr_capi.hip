@@ -196,8 +196,13 @@ int launchConvert(const bsmr_plan* p, uint32_t K, const float* A, const float* B
     const uint64_t total = nA8 + nB8;
     if (total == 0) return BSMR_OK;
     const uint64_t wgs = std::min<uint64_t>((total + bsmr::kThreads - 1) / bsmr::kThreads, 256 * 16);
+    // B converted by the XCD that gathers it afterwards, as long as the converted B fits the 8 x 4 MiB of L2 (nips-like
+    // K=128, 3.2 MB: 13.7 -> 12.8 us per SDDMM; reddit-like shard, 119 MB: nothing stays in L2 and the pass itself
+    // is 5 % slower when every XCD streams one contiguous eighth, 73.8 -> 78.0 us)
+    static const bool allowSliced = envInt("BSMR_CONVERT_SLICED", 1) != 0;
+    const bool sliced = allowSliced && nB8 * 16ull <= (32ull << 20);
     hipLaunchKernelGGL((bsmr::convertOperands<MODE>), dim3((unsigned)wgs), dim3(bsmr::kThreads), 0, s, A,
-                       nA8, B, nB8, A16, B16);
+                       nA8, B, nB8, A16, B16, sliced);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }

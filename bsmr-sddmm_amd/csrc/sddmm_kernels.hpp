@@ -83,31 +83,47 @@ __device__ __forceinline__ uint32_t xcdContiguous(uint32_t wg, uint32_t numWG) {
     return xcd * base + (xcd < rem ? xcd : rem) + idx;
 }
 
+template <int MODE>
+__device__ __forceinline__ u32x4 packLowp(const f32x4& lo, const f32x4& hi) {
+    if constexpr (MODE == 0) {
+        f16x8 o;
+        o[0] = (_Float16)lo[0]; o[1] = (_Float16)lo[1]; o[2] = (_Float16)lo[2]; o[3] = (_Float16)lo[3];
+        o[4] = (_Float16)hi[0]; o[5] = (_Float16)hi[1]; o[6] = (_Float16)hi[2]; o[7] = (_Float16)hi[3];
+        return __builtin_bit_cast(u32x4, o);
+    } else {
+        bf16x8 o;
+        o[0] = (__bf16)lo[0]; o[1] = (__bf16)lo[1]; o[2] = (__bf16)lo[2]; o[3] = (__bf16)lo[3];
+        o[4] = (__bf16)hi[0]; o[5] = (__bf16)hi[1]; o[6] = (__bf16)hi[2]; o[7] = (__bf16)hi[3];
+        return __builtin_bit_cast(u32x4, o);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // fp32 -> fp16 / bf16 operand pass (8 elements per thread, 16-byte stores)
 // ---------------------------------------------------------------------------
 template <int MODE>  // 0 = fp16, 1 = bf16
 __global__ void __launch_bounds__(kThreads)
 convertOperands(const float* __restrict__ A, uint64_t nA8, const float* __restrict__ B, uint64_t nB8,
-                uint16_t* __restrict__ A16, uint16_t* __restrict__ B16) {
-    const uint64_t total = nA8 + nB8;
-    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
-         i += (uint64_t)gridDim.x * kThreads) {
-        const float* src = i < nA8 ? A + i * 8 : B + (i - nA8) * 8;
-        uint16_t* dst = i < nA8 ? A16 + i * 8 : B16 + (i - nA8) * 8;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
-        if constexpr (MODE == 0) {
-            f16x8 o;
-            o[0] = (_Float16)lo[0]; o[1] = (_Float16)lo[1]; o[2] = (_Float16)lo[2]; o[3] = (_Float16)lo[3];
-            o[4] = (_Float16)hi[0]; o[5] = (_Float16)hi[1]; o[6] = (_Float16)hi[2]; o[7] = (_Float16)hi[3];
-            *reinterpret_cast<f16x8*>(dst) = o;
-        } else {
-            bf16x8 o;
-            o[0] = (__bf16)lo[0]; o[1] = (__bf16)lo[1]; o[2] = (__bf16)lo[2]; o[3] = (__bf16)lo[3];
-            o[4] = (__bf16)hi[0]; o[5] = (__bf16)hi[1]; o[6] = (__bf16)hi[2]; o[7] = (__bf16)hi[3];
-            *reinterpret_cast<bf16x8*>(dst) = o;
-        }
+                uint16_t* __restrict__ A16, uint16_t* __restrict__ B16, bool slicedB) {
+    // B is converted by the XCD that gathers it afterwards: the compute kernels give XCD x the x-th eighth of the
+    // column range (items in column order, xcdContiguous), so workgroup w (XCD w & 7) takes the pieces of that
+    // eighth of B and the converted lines are in the right L2 when the next kernel starts.  A goes first, in
+    // plain order (every XCD reads all of it).  Grids of fewer than 8 workgroups convert B in plain order.
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < nA8; i += (uint64_t)gridDim.x * kThreads) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(A + i * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(A + i * 8 + 4);
+        *reinterpret_cast<u32x4*>(A16 + i * 8) = packLowp<MODE>(lo, hi);
+    }
+    const bool sliced = slicedB && gridDim.x >= 8u;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint64_t slice = (nB8 + 7) / 8;
+    const uint64_t b0 = sliced ? min(nB8, slice * xcd) : 0, b1 = sliced ? min(nB8, b0 + slice) : nB8;
+    const uint64_t first = sliced ? blockIdx.x >> 3 : blockIdx.x;
+    const uint64_t stride = sliced ? (gridDim.x + 7u - xcd) >> 3 : gridDim.x;   // workgroups of this XCD
+    for (uint64_t i = b0 + first * kThreads + threadIdx.x; i < b1; i += stride * kThreads) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(B + i * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(B + i * 8 + 4);
+        *reinterpret_cast<u32x4*>(B16 + i * 8) = packLowp<MODE>(lo, hi);
     }
 }
 
@@ -600,20 +616,6 @@ denseGroupsAnyK(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B
 // would produce), so the full-matrix conversion pass can be skipped when only a
 // few blocks are dense.  One wave per DenseItem, fragments from global memory.
 // ---------------------------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ u32x4 packLowp(const f32x4& lo, const f32x4& hi) {
-    if constexpr (MODE == 0) {
-        f16x8 o;
-        o[0] = (_Float16)lo[0]; o[1] = (_Float16)lo[1]; o[2] = (_Float16)lo[2]; o[3] = (_Float16)lo[3];
-        o[4] = (_Float16)hi[0]; o[5] = (_Float16)hi[1]; o[6] = (_Float16)hi[2]; o[7] = (_Float16)hi[3];
-        return __builtin_bit_cast(u32x4, o);
-    } else {
-        bf16x8 o;
-        o[0] = (__bf16)lo[0]; o[1] = (__bf16)lo[1]; o[2] = (__bf16)lo[2]; o[3] = (__bf16)lo[3];
-        o[4] = (__bf16)hi[0]; o[5] = (__bf16)hi[1]; o[6] = (__bf16)hi[2]; o[7] = (__bf16)hi[3];
-        return __builtin_bit_cast(u32x4, o);
-    }
-}
 
 template <int MODE, typename TileT>
 __global__ void __launch_bounds__(kThreads)
