@@ -458,8 +458,12 @@ int checkCall(const bsmr_plan* p, uint32_t K, const void* A, const void* B, cons
 // all-sparse plan, residue entries x K large enough to repay a conversion pass over B (and the kernel boundary
 // after it): B alone is converted and the residue kernel rounds A's rows while it stages them in LDS
 inline bool convertsBOnly(const bsmr_plan* p, uint32_t K) {
-    return p->convertBOnly && (uint64_t)p->numSparseEntries * K * g_batch.count >= p->bOnlyWork &&
-           (size_t)16 * (2u * K + bsmr::kSparseLdsPad16) <= 64 * 1024;
+    if (!p->convertBOnly || (size_t)16 * (2u * K + bsmr::kSparseLdsPad16) > 64 * 1024) return false;
+    const uint64_t work = (uint64_t)p->numSparseEntries * K * g_batch.count;
+    // the pass costs ~N*K, the halved gather saves ~entries*K: patterns with >= 11 entries per column repay it from
+    // a third of the work (Trefethen_20000, 14 per column: K=128 15.3 -> 14.3 us, K=256 24.1 -> 22.0; wathen100,
+    // 8 per column: K=128 10.9 -> 12.9, K=256 20.5 -> 24.0 when forced, K=512 38.2 -> 36.8)
+    return work >= p->bOnlyWork || (p->numSparseEntries >= 11ull * p->N && work * 10 >= p->bOnlyWork * 3);
 }
 
 inline bool needsWorkspace(const bsmr_plan* p, int mode, uint32_t K) {
