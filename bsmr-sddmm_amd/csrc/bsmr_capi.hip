@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -20,6 +22,8 @@
 #include "plan_pack.hpp"
 #include "plan_promote.hpp"
 #include "sddmm_kernels.hpp"
+#include "tile_format.hpp"
+#include "tile_kernels.hpp"
 
 using bsmr::DenseItem;
 using bsmr::SparseItem;
@@ -45,6 +49,19 @@ struct DenseFormat {
     uint32_t streamWaves = 4;      // waves per workgroup of the streaming kernel (1: items of <= 8 blocks)
     bool stageInLds = false;       // assemble the row windows in LDS and write them out coalesced
     uint64_t numBlocks = 0, numTiles = 0, unionColumns = 0;
+};
+
+// Device-resident dense part in the "tiles" form for one group size (host layout: csrc/tile_format.hpp).
+struct TileFormatDev {
+    uint32_t H = 0;  // 0 = not built
+    uint32_t* groupRows = nullptr;
+    uint32_t* blockCols = nullptr;
+    uint32_t* blockInfo = nullptr;
+    uint32_t* entries = nullptr;
+    bsmr::TileItem* items = nullptr;
+    uint32_t* itemRowBase = nullptr;
+    uint32_t numItems = 0, entryCap = 0, blocksPerItem = 0;
+    uint64_t numBlocks = 0, numTiles = 0, unionColumns = 0, bytes = 0;
 };
 
 struct bsmr_plan {
@@ -86,6 +103,14 @@ struct bsmr_plan {
     uint64_t bOnlyWork = 0;        // ... residue entries x K from which that pays
     int denseBatch = 0;            // blocks per LDS batch at K = 128 (0 = default)
     bool useStream = true;         // streaming kernel for ungrouped plans (BSMR_DENSE_STREAM=0 disables)
+
+    // "tiles" engine: the dense entries on the host, census per group size, device formats built on first use
+    bsmr::HostDense hostDense;
+    bsmr::TileCensus census[4];    // H = 1, 2, 4, 8
+    TileFormatDev tiles[4];
+    bool useTiles = true;          // BSMR_DENSE_ENGINE=legacy: the r01 kernels
+    int forcedTileGroup = 0;       // BSMR_TILE_GROUP
+    int forcedTileBlocks = 0;      // BSMR_TILE_BLOCKS (blocks per work item)
 };
 
 namespace {
@@ -151,6 +176,30 @@ void freePlanDevice(bsmr_plan* p) {
     void* ptrs[] = {p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->entryRowId, p->sparseItems, p->A16, p->B16};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
+    for (TileFormatDev& t : p->tiles) {
+        void* tp[] = {t.groupRows, t.blockCols, t.blockInfo, t.entries, t.items, t.itemRowBase};
+        for (void* q : tp)
+            if (q) (void)hipFree(q);
+        t = TileFormatDev{};
+    }
+}
+
+int currentDevice() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) (void)hipGetLastError();
+    return d;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: raise it once per (kernel, device)
+int raiseDynamicLds(const void* kernel, size_t bytes, int device) {
+    if (bytes <= 64 * 1024) return BSMR_OK;
+    static std::mutex lock;
+    static std::set<std::pair<const void*, int>> raised;
+    std::lock_guard<std::mutex> guard(lock);
+    if (raised.count({kernel, device})) return BSMR_OK;
+    BSMR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised.insert({kernel, device});
+    return BSMR_OK;
 }
 
 int uploadDense(DenseFormat& f, const bsmr::PackedPlan& pk, uint64_t& bytes) {
@@ -215,12 +264,7 @@ int launchGroupsT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
     auto kernel = bsmr::denseGroups<KS, H, NB, MODE, TileT, LDS_STAGE>;
     // double-buffered batch of NB blocks (+ one 256-float window per group row when staged in LDS)
     const size_t lds = (size_t)2 * NB * 1024u * KS + (LDS_STAGE ? (size_t)H * 16u * 1024u : 0u);
-    static bool raised = false;  // per instantiation
-    if (lds > 64 * 1024 && !raised) {
-        BSMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        raised = true;
-    }
+    if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, currentDevice())) return st;
     hipLaunchKernelGGL(kernel, dim3(f.numItems, g_batch.count), dim3(bsmr::kThreads), lds, s, A16, B16, f.groupRows, f.rowBase,
                        f.winLen, f.winMask, f.blockCols, tiles, f.blockMask, f.items, P, g_batch);
     BSMR_HIP(hipGetLastError());
@@ -237,12 +281,7 @@ int launchStreamT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
     }
     auto kernel = bsmr::denseStream<KS, MODE, TileT, 8, WAVES, H>;
     const size_t lds = (size_t)WAVES * bsmr::streamSlots(KS) * 1024u * (KS > 8 ? 8 : KS);  // wave-private ring of images
-    static bool raised = false;
-    if (lds > 64 * 1024 && !raised) {
-        BSMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        raised = true;
-    }
+    if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, currentDevice())) return st;
     hipLaunchKernelGGL(kernel, dim3(f.numItems, g_batch.count), dim3(WAVES * bsmr::kWave), lds, s, A16, B16, f.groupRows, f.rowBase,
                        f.blockCols, tiles, f.items, P, g_batch);
     BSMR_HIP(hipGetLastError());
@@ -274,9 +313,191 @@ int launchGroupsH(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
     }
 }
 
+// ---- "tiles" engine (csrc/tile_format.hpp, csrc/tile_kernels.hpp) ---------------------------------------
+inline int tileSlot(uint32_t H) { return H == 1 ? 0 : H == 2 ? 1 : H == 4 ? 2 : 3; }
+
+// K for which denseTiles is instantiated, and the largest group whose A fragments fit the register budget
+// (H * K / 32 fragments of 4 VGPRs per lane; 32 fragments = 128 VGPRs)
+inline bool tilesServeK(uint32_t K) { return K == 32 || K == 64 || K == 128 || K == 256 || K == 512; }
+inline uint32_t tilesMaxGroup(uint32_t K) { return std::min<uint32_t>(bsmr::kTileMaxGroup, 32u / (K / 32u)); }
+
+// Panels per group for a call with inner dimension K.
+uint32_t chooseTileGroup(const bsmr_plan* p, uint32_t K) {
+    const uint32_t maxH = tilesMaxGroup(K);
+    const int forced = envInt("BSMR_TILE_GROUP", p->forcedTileGroup);   // (lab: re-read per call)
+    if (forced > 0) {
+        uint32_t h = 1;
+        while (h * 2 <= (uint32_t)forced && h * 2 <= maxH) h *= 2;
+        return h;
+    }
+    // cost per group size: bytes moved from L2 into the CU (B images + the A panels every work item loads)
+    // against MFMA issue; the smaller estimate wins, ties to the smaller group
+    uint32_t best = 1;
+    double bestCost = 0;
+    for (uint32_t h = 1; h <= maxH; h *= 2) {
+        const bsmr::TileCensus& c = p->census[tileSlot(h)];
+        if (c.blocks == 0) continue;
+        const double items = std::max<double>(1024.0, (double)c.blocks / 16.0);
+        const double bytes = (double)c.blocks * 32.0 * K + items * h * 32.0 * K;
+        const double gatherUs = bytes / 14e6;                              // ~14 TB/s of L2-served gathers
+        const double mfmaUs = (double)c.tiles * (K / 32.0) * 16.0 / 1024.0 / 2.1e3 / 0.6;  // 16 cycles per MFMA, 1024 SIMDs, ~60 % issue
+        const double cost = std::max(gatherUs, mfmaUs) + 0.25 * std::min(gatherUs, mfmaUs);
+        if (best == 1 && h == 1) bestCost = cost;
+        if (cost < bestCost * 0.97) {
+            best = h;
+            bestCost = cost;
+        }
+    }
+    return best;
+}
+
+int ensureTiles(bsmr_plan* p, uint32_t H) {
+    TileFormatDev& t = p->tiles[tileSlot(H)];
+    try {
+        const bsmr::TileCensus& c = p->census[tileSlot(H)];
+        // blocks per work item: enough items for two waves per SIMD, long enough to repay the A fragments
+        uint32_t perItem = (uint32_t)std::min<uint64_t>(bsmr::kTileMaxItemBlocks, std::max<uint64_t>(2 * H, c.blocks / 2048));
+        const int forcedBlocks = envInt("BSMR_TILE_BLOCKS", p->forcedTileBlocks);   // (lab: re-read per call)
+        if (forcedBlocks > 0) perItem = (uint32_t)std::min<int>(forcedBlocks, bsmr::kTileMaxItemBlocks);
+        if (t.H && t.blocksPerItem == perItem) return BSMR_OK;
+        if (t.H) {
+            void* tp[] = {t.groupRows, t.blockCols, t.blockInfo, t.entries, t.items, t.itemRowBase};
+            for (void* q : tp)
+                if (q) (void)hipFree(q);
+            p->indexBytes -= t.bytes;
+            t = TileFormatDev{};
+        }
+        bsmr::TileFormatHost host;
+        int st = bsmr::packTiles(p->hostDense, H, perItem, host);
+        if (st != BSMR_OK) return st;
+        uint64_t bytes = 0;
+        t.numItems = (uint32_t)host.items.size();
+        t.entryCap = host.entryCap;
+        t.blocksPerItem = perItem;
+        t.numBlocks = host.numBlocks;
+        t.numTiles = host.numTiles;
+        t.unionColumns = host.unionColumns;
+        st = upload(t.groupRows, host.groupRows, bytes);
+        if (st == BSMR_OK) st = upload(t.blockCols, host.blockCols, bytes);
+        if (st == BSMR_OK) st = upload(t.blockInfo, host.blockInfo, bytes);
+        if (st == BSMR_OK) st = upload(t.entries, host.entries, bytes);
+        if (st == BSMR_OK) st = upload(t.items, host.items, bytes);
+        if (st == BSMR_OK) st = upload(t.itemRowBase, host.itemRowBase, bytes);
+        if (st != BSMR_OK) {
+            void* tp[] = {t.groupRows, t.blockCols, t.blockInfo, t.entries, t.items, t.itemRowBase};
+            for (void* q : tp)
+                if (q) (void)hipFree(q);
+            t = TileFormatDev{};
+            return st;
+        }
+        t.bytes = bytes;
+        t.H = H;
+        p->indexBytes += bytes;
+        return BSMR_OK;
+    } catch (const std::bad_alloc&) {
+        return BSMR_ERR_OOM;
+    }
+}
+
+template <int KS, int H, int MODE, int DEPTH>
+int launchTilesD(const TileFormatDev& t, int device, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+    auto kernel = bsmr::denseTiles<KS, H, MODE, DEPTH>;
+    const size_t lds = bsmr::tileLdsBytes(KS, H, DEPTH, t.entryCap);
+    if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, device)) return st;
+#ifdef BSMR_LAB_STAMPS
+    if (envInt("BSMR_TILE_STAMPS", 0)) {   // lab: one stamped launch, phase statistics on stderr
+        uint64_t* dev = nullptr;
+        const size_t n = (size_t)t.numItems * 8;
+        BSMR_HIP(hipMalloc(reinterpret_cast<void**>(&dev), n * 8));
+        BSMR_HIP(hipMemset(dev, 0, n * 8));
+        hipLaunchKernelGGL(kernel, dim3(t.numItems, 1), dim3(bsmr::kWave), lds, s, A16, B16, t.groupRows, t.blockCols,
+                           reinterpret_cast<const uint2*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P, t.entryCap,
+                           g_batch, dev);
+        BSMR_HIP(hipStreamSynchronize(s));
+        std::vector<uint64_t> h(n);
+        BSMR_HIP(hipMemcpy(h.data(), dev, n * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(dev);
+        uint64_t first = ~0ull, last = 0;
+        for (uint32_t i = 0; i < t.numItems; ++i) {
+            first = std::min(first, h[(size_t)i * 8]);
+            last = std::max(last, h[(size_t)i * 8 + 4]);
+        }
+        auto med = [&](auto f) {
+            std::vector<double> v(t.numItems);
+            for (uint32_t i = 0; i < t.numItems; ++i) v[i] = f(&h[(size_t)i * 8]);
+            std::sort(v.begin(), v.end());
+            return std::make_pair(v[v.size() / 2], v[v.size() * 9 / 10]);
+        };
+        auto pr = [&](const char* name, std::pair<double, double> m) { fprintf(stderr, "  %-22s median %9.0f  p90 %9.0f\n", name, m.first, m.second); };
+        fprintf(stderr, "[tile stamps] KS=%d H=%d D=%d items=%u blocks=%llu lds=%zu span=%llu cycles (100 MHz ticks?)\n", KS, H, DEPTH,
+                t.numItems, (unsigned long long)t.numBlocks, lds, (unsigned long long)(last - first));
+        pr("start offset", med([&](const uint64_t* q) { return (double)(q[0] - first); }));
+        pr("prologue (meta)", med([&](const uint64_t* q) { return (double)(q[1] - q[0]); }));
+        pr("first image", med([&](const uint64_t* q) { return (double)(q[2] - q[1]); }));
+        pr("loop", med([&](const uint64_t* q) { return (double)(q[3] - q[2]); }));
+        pr("store drain", med([&](const uint64_t* q) { return (double)(q[4] - q[3]); }));
+        pr("  sum wait image", med([&](const uint64_t* q) { return (double)q[5]; }));
+        pr("  sum frag+mfma", med([&](const uint64_t* q) { return (double)q[6]; }));
+        pr("  sum slab+entries", med([&](const uint64_t* q) { return (double)q[7]; }));
+        pr("wave lifetime", med([&](const uint64_t* q) { return (double)(q[4] - q[0]); }));
+        return BSMR_OK;
+    }
+    hipLaunchKernelGGL(kernel, dim3(t.numItems, g_batch.count), dim3(bsmr::kWave), lds, s, A16, B16, t.groupRows,
+                       t.blockCols, reinterpret_cast<const uint2*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P,
+                       t.entryCap, g_batch, (uint64_t*)nullptr);
+#else
+    hipLaunchKernelGGL(kernel, dim3(t.numItems, g_batch.count), dim3(bsmr::kWave), lds, s, A16, B16, t.groupRows,
+                       t.blockCols, reinterpret_cast<const uint2*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P,
+                       t.entryCap, g_batch);
+#endif
+    BSMR_HIP(hipGetLastError());
+    return BSMR_OK;
+}
+
+template <int KS, int H, int MODE>
+int launchTilesT(const TileFormatDev& t, int device, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+    if constexpr (KS * H > 32) {
+        return BSMR_ERR_INVALID_ARG;
+    } else {
+        constexpr int D = (int)bsmr::tileDefaultDepth(KS);
+        if (envInt("BSMR_TILE_DEPTH", 0) == D + 1)   // (lab)
+            return launchTilesD<KS, H, MODE, D + 1>(t, device, A16, B16, P, s);
+        return launchTilesD<KS, H, MODE, D>(t, device, A16, B16, P, s);
+    }
+}
+
+template <int KS, int MODE>
+int launchTilesH(const TileFormatDev& t, int device, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+    switch (t.H) {
+    case 1: return launchTilesT<KS, 1, MODE>(t, device, A16, B16, P, s);
+    case 2: return launchTilesT<KS, 2, MODE>(t, device, A16, B16, P, s);
+    case 4: return launchTilesT<KS, 4, MODE>(t, device, A16, B16, P, s);
+    default: return launchTilesT<KS, 8, MODE>(t, device, A16, B16, P, s);
+    }
+}
+
+template <int MODE>
+int launchTiles(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+    const TileFormatDev& t = p->tiles[tileSlot(chooseTileGroup(p, K))];
+    if (!t.H) return BSMR_ERR_INVALID_ARG;   // ensureTiles runs before every launch path
+    if (t.numItems == 0) return BSMR_OK;
+    switch (K) {
+    case 32: return launchTilesH<1, MODE>(t, p->device, A16, B16, P, s);
+    case 64: return launchTilesH<2, MODE>(t, p->device, A16, B16, P, s);
+    case 128: return launchTilesH<4, MODE>(t, p->device, A16, B16, P, s);
+    case 256: return launchTilesH<8, MODE>(t, p->device, A16, B16, P, s);
+    default: return launchTilesH<16, MODE>(t, p->device, A16, B16, P, s);
+    }
+}
+
+inline bool tilesEngine(const bsmr_plan* p, uint32_t K) {
+    return p->useTiles && tilesServeK(K) && p->hostDense.entries() != 0 && !p->convertInKernel;
+}
+
 template <int MODE>
 int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
                   hipStream_t s) {
+    if (tilesEngine(p, K)) return launchTiles<MODE>(p, K, A16, B16, P, s);
     const DenseFormat& f = chooseFormat(p, K);
     if (f.numItems == 0) return BSMR_OK;
     if ((f.H == 1 || (f.H == 2 && f.streamWaves == 1)) && f.maxItemBlocks <= 32 && !f.stageInLds && p->useStream) {
@@ -468,6 +689,12 @@ inline bool convertsBOnly(const bsmr_plan* p, uint32_t K) {
 
 inline bool needsWorkspace(const bsmr_plan* p, int mode, uint32_t K) {
     return mode != BSMR_COMPUTE_F32 && (p->convertPass || convertsBOnly(p, K));
+}
+
+// device format of the dense part for calls with inner dimension K (allocates on first use)
+int prepareDense(bsmr_plan* p, uint32_t K) {
+    if (!tilesEngine(p, K)) return BSMR_OK;
+    return ensureTiles(p, chooseTileGroup(p, K));
 }
 
 int reserve(bsmr_plan* p, uint32_t K) {
@@ -755,6 +982,20 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
         if (p->sparseLpe != 4 && p->sparseLpe != 8 && p->sparseLpe != 16) p->sparseLpe = 0;
         p->denseBatch = envInt("BSMR_DENSE_BATCH", 0);
         p->useStream = envInt("BSMR_DENSE_STREAM", 1) != 0;
+        {
+            const char* engine = std::getenv("BSMR_DENSE_ENGINE");
+            p->useTiles = !(engine && std::string(engine) == "legacy");
+            p->forcedTileGroup = envInt("BSMR_TILE_GROUP", 0);
+            p->forcedTileBlocks = envInt("BSMR_TILE_BLOCKS", 0);
+            if (p->useTiles && pk.numBlocks) {
+                st = bsmr::collectDense(d, p->hostDense);
+                if (st != BSMR_OK) {
+                    delete p;
+                    return st;
+                }
+                for (uint32_t h = 1; h <= bsmr::kTileMaxGroup; h *= 2) p->census[tileSlot(h)] = bsmr::tileCensus(p->hostDense, h);
+            }
+        }
         // full conversion moves 6 bytes per operand element; the in-kernel path reads each
         // gathered element as fp32 (4 B, A re-read per block) from a slower kernel
         const int cvt = envInt("BSMR_CONVERT_IN_KERNEL", -1);
@@ -843,6 +1084,14 @@ int bsmr_plan_get_stats(const bsmr_plan* p, bsmr_plan_stats* out) {
 int bsmr_plan_dense_choice(const bsmr_plan* plan, uint32_t K, uint32_t* group_size, uint64_t* tiles,
                            uint64_t* union_columns) {
     if (!plan) return BSMR_ERR_INVALID_ARG;
+    if (tilesEngine(plan, K)) {
+        const uint32_t h = chooseTileGroup(plan, K);
+        const bsmr::TileCensus& c = plan->census[tileSlot(h)];
+        if (group_size) *group_size = h;
+        if (tiles) *tiles = c.tiles;
+        if (union_columns) *union_columns = c.unionColumns;
+        return BSMR_OK;
+    }
     const DenseFormat& f = chooseFormat(plan, K);
     if (group_size) *group_size = f.H ? f.H : 1;
     if (tiles) *tiles = f.numTiles;
@@ -877,6 +1126,7 @@ int bsmr_plan_reserve(bsmr_plan* plan, uint32_t K) {
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     BSMR_HIP(hipSetDevice(plan->device));
+    if (int st = prepareDense(plan, K)) return st;
     if (!plan->convertPass && !convertsBOnly(plan, K)) return BSMR_OK;
     return reserve(plan, K);
 }
@@ -886,6 +1136,7 @@ int bsmr_sddmm(bsmr_plan* plan, uint32_t K, const float* A, const float* B, floa
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     BSMR_HIP(hipSetDevice(plan->device));
+    if (mode != BSMR_COMPUTE_F32 && (st = prepareDense(plan, K)) != BSMR_OK) return st;
     if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;
     return runPieces(plan, K, A, B, P, mode, static_cast<hipStream_t>(stream), 7);
 }
@@ -902,6 +1153,7 @@ int bsmr_sddmm_batch(bsmr_plan* plan, uint32_t K, const float* A, const float* B
         ~Restore() { g_batch = bsmr::Batch{0, 0, 0, 1}; }
     } restore;
     g_batch = bsmr::Batch{(uint64_t)plan->M * K, (uint64_t)plan->N * K, plan->nnz, num_batches};
+    if (mode != BSMR_COMPUTE_F32 && (st = prepareDense(plan, K)) != BSMR_OK) return st;
     if (needsWorkspace(plan, mode, K)) {
         // the batches are contiguous, so one conversion pass covers all of them
         if ((st = reserve(plan, K * num_batches)) != BSMR_OK) return st;
@@ -946,6 +1198,7 @@ int bsmr_sddmm_lowp(bsmr_plan* plan, uint32_t K, const void* A16, const void* B1
     if (plan->numSparseItems && !residueLowp && (!A || !B)) return BSMR_ERR_INVALID_ARG;  // fp32 residue
     BSMR_HIP(hipSetDevice(plan->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int pst = prepareDense(plan, K)) return pst;
     int st = mode == BSMR_COMPUTE_F16
                  ? launchDense16<0>(plan, K, static_cast<const uint16_t*>(A16),
                                     static_cast<const uint16_t*>(B16), P, s)
@@ -965,6 +1218,7 @@ int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     if (st != BSMR_OK) return st;
     if (!out || iters <= 0 || warmup < 0) return BSMR_ERR_INVALID_ARG;
     BSMR_HIP(hipSetDevice(plan->device));
+    if (mode != BSMR_COMPUTE_F32 && (st = prepareDense(plan, K)) != BSMR_OK) return st;
     if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipEvent_t e0 = nullptr, e1 = nullptr;

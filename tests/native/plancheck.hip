@@ -7,6 +7,7 @@
 
 #include "plan_pack.hpp"
 #include "plan_promote.hpp"
+#include "tile_format.hpp"
 
 namespace {
 double nowUs() {
@@ -102,5 +103,82 @@ extern "C" int plancheck_promote(const bsmr_rphm_desc* in, uint32_t minAverage, 
     out[12] = !pk.tiles8.empty() ? 1 : !pk.tiles16.empty() ? 2 : !pk.tiles32.empty() ? 4 : 0;
     out[6] = pk.numDenseEntries;
     out[7] = pk.numSparseEntries;
+    return 0;
+}
+
+// The "tiles" dense format (csrc/tile_format.hpp) packed for H panels per group and checked the way the kernel reads
+// it: every dense entry of the RPHM is listed exactly once, in a block that holds its column at the listed slot, on
+// the listed row of its group, and row base + offset is its CSR index; entry lists start on multiples of 4 and are
+// ordered by (row, column); a block's mask has exactly the panels that own an entry; counts fit the LDS room.
+// out[0] blocks, [1] tiles, [2] union columns, [3] entries, [4] items, [5] entry cap, [6] bytes, [7..9] census blocks / tiles / columns.
+extern "C" int plancheck_tiles(const bsmr_rphm_desc* d, uint32_t H, uint32_t blocksPerItem, uint64_t* out) {
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    bsmr::HostDense hd;
+    int st = bsmr::collectDense(d, hd);
+    if (st != BSMR_OK) return 100 + st;
+    bsmr::TileFormatHost f;
+    st = bsmr::packTiles(hd, H, blocksPerItem, f);
+    if (st != BSMR_OK) return 200 + st;
+    const bsmr::TileCensus census = bsmr::tileCensus(hd, H);
+    out[0] = f.numBlocks; out[1] = f.numTiles; out[2] = f.unionColumns; out[3] = f.numEntries;
+    out[4] = f.items.size(); out[5] = f.entryCap; out[6] = f.bytes();
+    out[7] = census.blocks; out[8] = census.tiles; out[9] = census.unionColumns;
+    const uint32_t R = 16 * H;
+    // expected: CSR index -> (original row, column) from the RPHM
+    std::vector<uint32_t> wantRow(d->nnz, kNone), wantCol(d->nnz, kNone);
+    uint64_t denseEntries = 0;
+    for (uint32_t p = 0; p < d->num_row_panels; ++p)
+        for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b)
+            for (uint32_t i = 0; i < 256; ++i) {
+                const uint32_t v = d->block_values[b * 256 + i];
+                if (v == kNone) continue;
+                const size_t slot = (size_t)p * 16 + i / 16;
+                wantRow[v] = slot < d->num_nonzero_rows ? d->reordered_rows[slot] : kNone;
+                wantCol[v] = d->dense_cols[b * 16 + i % 16];
+                ++denseEntries;
+            }
+    if (f.numEntries != denseEntries) return 1;
+    std::vector<uint8_t> seen(d->nnz, 0);
+    std::vector<uint8_t> blockSeen(f.numBlocks, 0);
+    uint64_t tiles = 0, cols = 0;
+    for (size_t it = 0; it < f.items.size(); ++it) {
+        const bsmr::TileItem& item = f.items[it];
+        if (item.count == 0 || item.count > bsmr::kTileMaxItemBlocks || item.first + item.count > f.numBlocks) return 2;
+        if (it && f.blockCols[(size_t)f.items[it - 1].first * 16] > f.blockCols[(size_t)item.first * 16]) return 3;  // column order
+        for (uint32_t b = item.first; b < item.first + item.count; ++b) {
+            if (blockSeen[b]++) return 4;
+            const uint32_t start = f.blockInfo[2 * (size_t)b], mask = f.blockInfo[2 * (size_t)b + 1] & 0xFFFFu;
+            const uint32_t n = f.blockInfo[2 * (size_t)b + 1] >> 16;
+            if (start % 4 || n == 0 || n > f.entryCap || (size_t)start + (n + 255) / 256 * 256 > f.entries.size()) return 5;
+            uint32_t got = 0, last = 0;
+            for (uint32_t e = 0; e < n; ++e) {
+                const uint32_t w = f.entries[start + e];
+                const uint32_t row = w & 127u, slot = (w >> 7) & 15u, off = w >> 11;
+                if (row >= R) return 6;
+                const uint32_t idx = f.itemRowBase[it * R + row] + off;
+                if (idx >= d->nnz || seen[idx]++) return 7;
+                if (f.groupRows[(size_t)item.group * R + row] != wantRow[idx]) return 8;
+                if (f.blockCols[(size_t)b * 16 + slot] != wantCol[idx]) return 9;
+                const uint32_t key = row * 16 + slot;
+                if (e && key < last) return 10;   // (row, column) order
+                last = key;
+                got |= 1u << (row / 16);
+            }
+            if (got != mask) return 11;
+            tiles += __builtin_popcount(mask);
+            for (uint32_t c = 0; c < 16; ++c) {
+                if (c && f.blockCols[(size_t)b * 16 + c] != 0 && f.blockCols[(size_t)b * 16 + c] <= f.blockCols[(size_t)b * 16 + c - 1]) return 12;
+                if (f.blockCols[(size_t)b * 16 + c] >= d->N) return 13;
+            }
+        }
+    }
+    for (uint64_t b = 0; b < f.numBlocks; ++b)
+        if (!blockSeen[b]) return 14;
+    for (uint32_t v = 0; v < d->nnz; ++v)
+        if ((wantRow[v] != kNone) != (seen[v] != 0)) return 15;
+    if (tiles != f.numTiles) return 16;
+    (void)cols;
+    if (census.blocks > f.numBlocks || census.unionColumns != f.unionColumns) return 17;   // (blocks cut at the entry cap add to the census)
+    if (census.blocks == f.numBlocks && census.tiles != f.numTiles) return 18;
     return 0;
 }

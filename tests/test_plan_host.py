@@ -46,6 +46,66 @@ def plancheck(engine):
     return run
 
 
+@pytest.fixture(scope="module")
+def tilecheck(engine):
+    lib = C.CDLL(str(REPO / "tests" / "native" / "libplancheck.so"))
+    lib.plancheck_tiles.restype = C.c_int
+    lib.plancheck_tiles.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+
+    def run(rows, cols, ro, ci, alpha, delta, H, blocks_per_item):
+        csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+        pipe = engine.Pipeline(csr, alpha=alpha, delta=delta, device=-1)
+        arrays = pipe.arrays()
+        keep = {k: np.ascontiguousarray(arrays[k], dtype=np.uint32) for k in
+                ("reorderedRows", "denseCols", "blockOffsets", "blockValues", "sparseValueOffsets",
+                 "sparseValues", "sparseRelativeRows", "sparseColIndices")}
+        d = engine.RphmDesc()
+        d.M, d.N, d.nnz = rows, cols, csr.nnz
+        d.num_nonzero_rows = keep["reorderedRows"].size
+        d.num_row_panels = keep["blockOffsets"].size - 1
+        cast = lambda a: a.ctypes.data_as(engine.u32p)
+        d.reordered_rows, d.dense_cols = cast(keep["reorderedRows"]), cast(keep["denseCols"])
+        d.block_offsets, d.block_values = cast(keep["blockOffsets"]), cast(keep["blockValues"])
+        d.sparse_value_offsets, d.sparse_values = cast(keep["sparseValueOffsets"]), cast(keep["sparseValues"])
+        d.sparse_relative_rows, d.sparse_col_indices = cast(keep["sparseRelativeRows"]), cast(keep["sparseColIndices"])
+        out = (C.c_uint64 * 10)()
+        rc = lib.plancheck_tiles(C.byref(d), H, blocks_per_item, out)
+        names = ("blocks", "tiles", "union_columns", "entries", "items", "entry_cap", "bytes", "census_blocks",
+                 "census_tiles", "census_columns")
+        res = dict(zip(names, (int(v) for v in out)))
+        res["rphm_dense"] = int(csr.nnz - keep["sparseValues"].size)
+        return rc, res
+    return run
+
+
+@pytest.mark.parametrize("H", [1, 2, 4, 8])
+@pytest.mark.parametrize("blocks_per_item", [1, 5, 32])
+def test_tiles_format_lists_every_dense_entry_once(tilecheck, H, blocks_per_item):
+    """csrc/tile_format.hpp: the packed format, read the way the kernel reads it, reproduces the RPHM's dense part."""
+    rows, cols, ro, ci = synth.nips_like(rows=330, cols=1500, nnz=42000, seed=3)   # 21 panels: a ragged last group
+    for delta in (0.0, 0.1):
+        rc, r = tilecheck(rows, cols, ro, ci, 0.3, delta, H, blocks_per_item)
+        assert rc == 0, f"invariant {rc} violated: {r}"
+        assert r["entries"] == r["rphm_dense"]
+        assert r["blocks"] * 16 >= r["union_columns"] > (r["blocks"] - r["items"]) * 16 - 16 * r["items"]
+    # grouping never gathers more columns, and never fewer than one panel's worth
+    sizes = [tilecheck(rows, cols, ro, ci, 0.3, 0.0, h, 8)[1]["union_columns"] for h in (1, 2, 4, 8)]
+    assert sizes == sorted(sizes, reverse=True) and sizes[3] * 8 >= sizes[0]
+
+
+def test_tiles_format_cuts_blocks_at_the_entry_cap(tilecheck):
+    """A block may hold at most 128 entries per panel of the group (the LDS room of the kernel): fuller blocks are
+    cut at a column boundary."""
+    rows, cols = 128, 64
+    ro = np.arange(rows + 1, dtype=np.uint32) * cols
+    ci = np.tile(np.arange(cols, dtype=np.uint32), rows)          # a full matrix: 256 entries per 16x16 tile
+    for H in (1, 4, 8):
+        rc, r = tilecheck(rows, cols, ro, ci, 0.3, 0.0, H, 4)
+        assert rc == 0, (rc, r)
+        assert r["entries"] == rows * cols and r["entry_cap"] <= 128 * H + 16 * H + 255
+        assert r["blocks"] > r["census_blocks"]                   # blocks of 8 columns instead of 16
+
+
 @pytest.mark.parametrize("min_average,head", [(1, 0), (8, 0), (20, 0), (40, 0), (40, 12), (200, 6)])
 @pytest.mark.parametrize("delta", [0.05, 0.3, 1.1])
 def test_promotion_keeps_every_entry_exactly_once(plancheck, min_average, head, delta):
