@@ -5,10 +5,12 @@
 // 16*H rows) is stored as
 //   blockCols [16]   the group's union of dense columns, ascending column id, cut into 16s
 //                    (padding -> column 0, never written)
-//   blockInfo        {first entry, panel mask | entry count << 16}: bit h of the mask = panel h has an
-//                    entry in the block (tiles without entries are not multiplied)
+//   blockInfo [4]    {first entry, panel mask | entry count << 16, c0 | c1 << 16, c2 | c3 << 16}: bit h of the
+//                    mask = panel h has an entry in the block (tiles without entries are not multiplied);
+//                    c_w = entries on the w-th quarter of the group's rows (the four waves of the shared-B
+//                    kernel own a quarter each; entries are ordered by row, so a quarter is a sub-range)
 //   entries   [u32]  one word per stored entry of the block, ordered by (row, column):
-//                    row in group (7 bits) | column slot (4 bits) << 7 | offset (21 bits) << 11,
+//                    row in group (8 bits) | column slot (4 bits) << 8 | offset (20 bits) << 12,
 //                    offset = CSR index minus the work item's base for that row (itemRowBase)
 // so the destination metadata is 4 bytes per ENTRY (the r01 format: 256 bytes per (panel, block) tile,
 // whatever it held) and does not grow when panels are grouped.  The kernel (tile_kernels.hpp) multiplies
@@ -29,9 +31,9 @@
 
 namespace bsmr {
 
-constexpr uint32_t kTileMaxGroup = 8;         // panels per group the kernels are built for
-constexpr uint32_t kTileMaxItemBlocks = 16;   // blocks per work item (column ids of an item sit in LDS)
-constexpr uint32_t kTileOffsetBits = 21;      // entry offset from the item's row base
+constexpr uint32_t kTileMaxGroup = 16;        // panels per group the kernels are built for
+constexpr uint32_t kTileMaxItemBlocks = 32;   // blocks per work item (column ids of an item sit in LDS)
+constexpr uint32_t kTileOffsetBits = 20;      // entry offset from the item's row base
 constexpr uint32_t kTileEntryChunk = 256;     // entries one LDS-DMA instruction moves (64 lanes x 16 B)
 
 struct TileItem {
@@ -57,7 +59,7 @@ struct TileFormatHost {
     uint32_t entryCap = 64;                    // LDS room for a block's entry words: max entries per block, rounded up to 64
     std::vector<uint32_t> groupRows;           // [G*16H]
     std::vector<uint32_t> blockCols;           // [NB*16]
-    std::vector<uint32_t> blockInfo;           // [NB*2]
+    std::vector<uint32_t> blockInfo;           // [NB*4]
     std::vector<uint32_t> entries;             // every block's list padded to a multiple of 4, + one chunk at the end
     std::vector<TileItem> items;
     std::vector<uint32_t> itemRowBase;         // [items*16H]
@@ -251,8 +253,12 @@ inline int packTiles(const HostDense& hd, uint32_t H, uint32_t blocksPerItem, Ti
                 }
                 const uint32_t count = (uint32_t)(i - b0);   // <= cap + 16H: fits the 16-bit count field
                 for (uint32_t c = 0; c < 16; ++c) go.cols.push_back(c < ncols ? cols[c] : 0u);
+                uint32_t quarter[4] = {0, 0, 0, 0};
+                for (size_t e = b0; e < i; ++e) ++quarter[keys[e].row / (4u * H)];
                 go.info.push_back((uint32_t)b0);   // patched to the global entry index below
                 go.info.push_back(mask | (count << 16));
+                go.info.push_back(quarter[0] | (quarter[1] << 16));
+                go.info.push_back(quarter[2] | (quarter[3] << 16));
                 go.tiles += __builtin_popcount(mask);
                 go.unionColumns += ncols;
                 go.maxEntries = std::max(go.maxEntries, count);
@@ -271,7 +277,7 @@ inline int packTiles(const HostDense& hd, uint32_t H, uint32_t blocksPerItem, Ti
                     go.rowBase[rb + keys[e].row] = std::min(go.rowBase[rb + keys[e].row], keys[e].idx);
                 for (uint32_t b = first; b < first + count; ++b) {
                     const uint32_t e0 = blockStart[b], e1 = blockStart[b + 1];
-                    go.info[2 * (size_t)b] = (uint32_t)go.entries.size();   // group-local, multiple of 4
+                    go.info[4 * (size_t)b] = (uint32_t)go.entries.size();   // group-local, multiple of 4
                     const uint32_t* cols = &go.cols[(size_t)b * 16];
                     const uint32_t used = blockNcols[b];   // columns ascending, padding (0) only behind them
                     sorted.assign(keys.begin() + e0, keys.begin() + e1);
@@ -282,7 +288,7 @@ inline int packTiles(const HostDense& hd, uint32_t H, uint32_t blocksPerItem, Ti
                         const uint32_t slot = (uint32_t)(std::lower_bound(cols, cols + used, k.col) - cols);
                         const uint32_t off = k.idx - go.rowBase[rb + k.row];
                         if (off >> kTileOffsetBits) go.overflow = true;
-                        go.entries.push_back(k.row | (slot << 7) | (off << 11));
+                        go.entries.push_back(k.row | (slot << 8) | (off << 12));
                     }
                     while (go.entries.size() & 3u) go.entries.push_back(0u);
                 }
@@ -296,23 +302,25 @@ inline int packTiles(const HostDense& hd, uint32_t H, uint32_t blocksPerItem, Ti
     uint64_t nb = 0, ne = 0, ni = 0;
     for (const GroupOut& go : groups) {
         if (go.overflow) return BSMR_ERR_BAD_PLAN;   // offsets beyond 2^21 of one row inside an item: not representable
-        nb += go.info.size() / 2;
+        nb += go.info.size() / 4;
         ne += go.entries.size();
         ni += go.items.size();
     }
     if (ne + kTileEntryChunk > 0xFFFFFFF0ull || nb > 0xFFFFFFF0ull) return BSMR_ERR_BAD_PLAN;
     out.blockCols.reserve(nb * 16);
-    out.blockInfo.reserve(nb * 2);
+    out.blockInfo.reserve(nb * 4);
     out.entries.reserve(ne + kTileEntryChunk);
     out.items.reserve(ni);
     out.itemRowBase.reserve(ni * R);
     uint32_t maxEntries = 0;
     for (GroupOut& go : groups) {
-        const uint32_t blockBase = (uint32_t)(out.blockInfo.size() / 2), entryBase = (uint32_t)out.entries.size();
+        const uint32_t blockBase = (uint32_t)(out.blockInfo.size() / 4), entryBase = (uint32_t)out.entries.size();
         out.blockCols.insert(out.blockCols.end(), go.cols.begin(), go.cols.end());
-        for (size_t b = 0; b < go.info.size() / 2; ++b) {
-            out.blockInfo.push_back(go.info[2 * b] + entryBase);
-            out.blockInfo.push_back(go.info[2 * b + 1]);
+        for (size_t b = 0; b < go.info.size() / 4; ++b) {
+            out.blockInfo.push_back(go.info[4 * b] + entryBase);
+            out.blockInfo.push_back(go.info[4 * b + 1]);
+            out.blockInfo.push_back(go.info[4 * b + 2]);
+            out.blockInfo.push_back(go.info[4 * b + 3]);
         }
         out.entries.insert(out.entries.end(), go.entries.begin(), go.entries.end());
         for (TileItem it : go.items) {
@@ -328,7 +336,7 @@ inline int packTiles(const HostDense& hd, uint32_t H, uint32_t blocksPerItem, Ti
         GroupOut().entries.swap(go.entries);
     }
     out.entries.resize(out.entries.size() + kTileEntryChunk, 0u);   // the last block's DMA reads whole chunks
-    out.numBlocks = out.blockInfo.size() / 2;
+    out.numBlocks = out.blockInfo.size() / 4;
     out.entryCap = std::max(64u, (maxEntries + 63u) / 64u * 64u);   // LDS room per block: whole 256-byte lines
     // items in the order of their first column: XCD x executes the x-th eighth of the list and keeps one column
     // range of B in its L2 (as in the r01 format); the per-item row bases are permuted along

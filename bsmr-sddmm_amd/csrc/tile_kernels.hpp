@@ -115,7 +115,7 @@ template <int KS, int H, int MODE, int DEPTH>
 __global__ void __launch_bounds__(kWave)
 denseTiles(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
            const uint32_t* __restrict__ groupRows, const uint32_t* __restrict__ blockCols,
-           const uint2* __restrict__ blockInfo, const uint32_t* __restrict__ entries,
+           const uint4* __restrict__ blockInfo, const uint32_t* __restrict__ entries,
            const TileItem* __restrict__ items, const uint32_t* __restrict__ itemRowBase,
            float* __restrict__ P, uint32_t entryCap, Batch batch
 #ifdef BSMR_LAB_STAMPS
@@ -135,7 +135,7 @@ denseTiles(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     constexpr uint32_t D = (uint32_t)DEPTH;
     constexpr uint32_t DE = tileEntrySlots(KS, D);
     constexpr uint32_t R = 16u * H;
-    static_assert(H >= 1 && H <= (int)kTileMaxGroup && D >= 2, "panels per group / ring depth");
+    static_assert(H >= 1 && H <= 8 && D >= 2, "panels per group / ring depth");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* const ring = lds;                                                   // [D] images
@@ -173,7 +173,7 @@ denseTiles(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
                                              (__attribute__((address_space(3))) void*)(rowBaseLds + j * 64u), 4, 0, 0);
         }
     }
-    const uint2 info = blockInfo[item.first + (lane < count ? lane : 0u)];   // lane m: block m of the item
+    const uint4 info = blockInfo[item.first + (lane < count ? lane : 0u)];   // lane m: block m of the item
     uint32_t myRow[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) myRow[h] = groupRows[(size_t)item.group * R + 16u * h + r];
@@ -335,7 +335,7 @@ denseTiles(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
         for (uint32_t q = 0; q < RMAX; ++q)
             if (q * kWave < n) {
                 w[q] = q * kWave + lane < n ? w[q] : 0u;   // lanes past the end: a harmless slot
-                const uint32_t row = w[q] & 127u, col = (w[q] >> 7) & 15u;
+                const uint32_t row = w[q] & 255u, col = (w[q] >> 8) & 15u;
                 src[q] = row * kSlabStride + col;
                 base[q] = rowBaseLds[row];
             }
@@ -351,12 +351,12 @@ denseTiles(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
             if (q * kWave < n) val[q] = slab[src[q]];
 #pragma unroll
         for (uint32_t q = 0; q < RMAX; ++q)
-            if (q * kWave + lane < n) P[base[q] + (w[q] >> 11)] = val[q];
+            if (q * kWave + lane < n) P[base[q] + (w[q] >> 12)] = val[q];
 #pragma unroll 1
         for (uint32_t e = RMAX * kWave + lane; e < n; e += kWave) {   // blocks with more entries (rare)
             const uint32_t word = entWords[e];
-            const uint32_t row = word & 127u, col = (word >> 7) & 15u;
-            P[rowBaseLds[row] + (word >> 11)] = slab[row * kSlabStride + col];
+            const uint32_t row = word & 255u, col = (word >> 8) & 15u;
+            P[rowBaseLds[row] + (word >> 12)] = slab[row * kSlabStride + col];
         }
         issued += (n + kWave - 1u) / kWave;   // one store instruction per round of 64 entries
         BSMR_STAMP_ACC(2, tPhase);           // slab + entries + store issue

@@ -106,6 +106,7 @@ public:
     // Device-resident form (nullptr when built with device < 0 or when plan
     // creation failed; planStatus() then holds the bsmr_hip.h status code).
     bsmr_plan* plan() const { return plan_; }
+    int device() const { return device_; }
     int planStatus() const { return planStatus_; }
 
     UIN calculateRowPanelIdByBlockValuesIndex(UIN blockValueIndex) const;
@@ -145,6 +146,7 @@ private:
     float reorderingTime_ = 0.0f;
     bsmr_plan* plan_ = nullptr;
     int planStatus_ = 0;
+    int device_ = 0;
 };
 
 // Identity order over the non-empty rows (reference src/rowReordering.cu:15-46).
@@ -171,6 +173,11 @@ UIN calculateBlockSize(const sparseMatrix::CSR<float>& matrix, size_t freeDevice
 //   >= 0        : that device (falls back to the host when the table does not fit)
 void setClusteringDevice(int device);
 int clusteringDevice();
+// The device the automatic rule above, calculateBlockSize's free-memory query and the launchers' synchronisation use
+// (per thread, default 0): a process that drives several GPUs - one pipeline per rank or per shard - sets it to the
+// pipeline's device, so that no rank clusters on, allocates on or leaves the process on GPU 0.
+void setPipelineDevice(int device);
+int pipelineDevice();
 
 // bsa_rowReordering_gpu of the reference (src/rowReordering.cu:1027-1095) on the MI355X:
 // csrc/cluster_kernels.hpp through bsmr_cluster_rows.  Returns false when the device path is

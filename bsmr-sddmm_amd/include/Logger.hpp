@@ -93,6 +93,7 @@ struct Logger {
     float convertTime_ = 0.0f;
     float denseTime_ = 0.0f;
     float sparseTime_ = 0.0f;
+    int status_ = 0;              // bsmr_hip.h status of the device call behind the numbers above (0 = success)
 };
 
 void Logger::printLogInformation(std::ostream& out) const {
@@ -143,6 +144,7 @@ void Logger::printLogInformation(std::ostream& out) const {
     out << "[mi355x_compute : " << computeMode_ << "]\n";
     out << std::fixed << std::setprecision(3);
     out << "[mi355x_sddmm_us : " << sddmmTime_ * 1e3f << "]\n";
+    out << "[mi355x_status : " << status_ << "]\n";
     out << "[mi355x_convert_us : " << convertTime_ * 1e3f << "]\n";
     out << "[mi355x_dense_us : " << denseTime_ * 1e3f << "]\n";
     out << "[mi355x_sparse_us : " << sparseTime_ * 1e3f << "]\n";

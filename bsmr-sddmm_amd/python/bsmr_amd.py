@@ -55,6 +55,19 @@ class PlanStats(C.Structure):
                 ("promoted_sparse_entries", C.c_uint64)]
 
 
+class PlanOptions(C.Structure):
+    """bsmr_plan_options (include/bsmr_hip.h): every rule of plan construction that is not in the RPHM arrays"""
+    _fields_ = [("struct_size", C.c_uint32)] + [(name, C.c_int32) for name in (
+        "dense_engine", "fold_dense_below", "promote_average", "promote_min_entries_k", "promote_column_degree",
+        "promote_head", "dense_group", "dense_blocks_per_item", "stream_waves", "output_mode", "force_tile32",
+        "column_order", "dense_stream", "dense_batch", "tile_group", "tile_blocks_per_item", "tile_depth",
+        "sparse_entries_per_item", "sparse_lowp", "sparse_lpe", "free_residue", "convert_in_kernel", "convert_sliced",
+        "b_only", "b_only_work_m", "overlap_streams")]
+
+
+ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED = 0, 1, 2
+
+
 class ReorderingReport(C.Structure):
     _fields_ = [("original_num_dense_blocks", C.c_int32), ("original_average_density", C.c_float),
                 ("num_dense_blocks", C.c_int32), ("average_density", C.c_float),
@@ -87,6 +100,9 @@ HIP_SYMBOLS = {
     "bsmr_dev_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
     "bsmr_device_synchronize": (C.c_int, [C.c_int]),
     "bsmr_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RphmDesc)]),
+    "bsmr_plan_create_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RphmDesc), C.POINTER(PlanOptions)]),
+    "bsmr_plan_options_default": (C.c_int, [C.POINTER(PlanOptions)]),
+    "bsmr_plan_options_from_env": (C.c_int, [C.POINTER(PlanOptions)]),
     "bsmr_plan_destroy": (C.c_int, [C.c_void_p]),
     "bsmr_plan_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
     "bsmr_cluster_rows": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float,
@@ -424,9 +440,21 @@ def sddmm_host(plan, K, A: np.ndarray, B: np.ndarray, nnz: int, mode=COMPUTE_F16
     return P, ms.value
 
 
-def plan_from_arrays(M, N, nnz, arrays: dict, device=0):
+def plan_options(**changes) -> PlanOptions:
+    """bsmr_plan_options_default with fields changed by keyword"""
+    o = PlanOptions()
+    _check(hip().bsmr_plan_options_default(C.byref(o)), "bsmr_plan_options_default")
+    for k, v in changes.items():
+        if k not in dict(PlanOptions._fields_):
+            raise KeyError(k)
+        setattr(o, k, v)
+    return o
+
+
+def plan_from_arrays(M, N, nnz, arrays: dict, device=0, options: PlanOptions = None):
     """bsmr_plan_create straight from RPHM-layout numpy arrays (what a reference
-    maintainer would pass from RPHM's host vectors).  Returns the plan handle."""
+    maintainer would pass from RPHM's host vectors).  Returns the plan handle.
+    options: a PlanOptions -> bsmr_plan_create_ex (the environment is then not consulted)."""
     keep = {k: np.ascontiguousarray(arrays[k], dtype=np.uint32) for k in
             ("reorderedRows", "denseCols", "blockOffsets", "blockValues", "sparseValueOffsets",
              "sparseValues", "sparseRelativeRows", "sparseColIndices")}
@@ -444,7 +472,10 @@ def plan_from_arrays(M, N, nnz, arrays: dict, device=0):
     d.sparse_relative_rows = cast(keep["sparseRelativeRows"])
     d.sparse_col_indices = cast(keep["sparseColIndices"])
     out = C.c_void_p()
-    st = hip().bsmr_plan_create(C.byref(out), device, C.byref(d))
+    if options is not None:
+        st = hip().bsmr_plan_create_ex(C.byref(out), device, C.byref(d), C.byref(options))
+    else:
+        st = hip().bsmr_plan_create(C.byref(out), device, C.byref(d))
     return st, out
 
 

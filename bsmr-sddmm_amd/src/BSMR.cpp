@@ -87,7 +87,7 @@ void BSMR::rowReordering(const float similarityThreshold, const sparseMatrix::CS
             UIN nonEmpty = 0;
             for (UIN r = 0; r < matrix.row(); ++r) nonEmpty += matrix.rowOffsets()[r + 1] > matrix.rowOffsets()[r];
             const bool longRows = nonEmpty && matrix.nnz() / nonEmpty >= 32;
-            device = present && (choice == "device" || longRows) ? 0 : -1;
+            device = present && (choice == "device" || longRows) ? std::min(pipelineDevice(), count - 1) : -1;
         }
         if (device < 0 ||
             !bsa_rowReordering_device(matrix, similarityThreshold, blockSize, device, reorderedRows_, numClusters_, once))
@@ -190,6 +190,7 @@ RPHM::RPHM(const sparseMatrix::CSR<float>& matrix, const BSMR& bsmr, int device)
     }
     reorderingTime_ = std::chrono::duration<float, std::milli>(Clock::now() - t0).count();
 
+    device_ = device < 0 ? 0 : device;
     if (device >= 0) {
         bsmr_rphm_desc d{};
         d.M = matrix.row();
@@ -247,6 +248,7 @@ RPHM& RPHM::operator=(RPHM&& o) noexcept {
     reorderingTime_ = o.reorderingTime_;
     plan_ = o.plan_;
     planStatus_ = o.planStatus_;
+    device_ = o.device_;
     o.plan_ = nullptr;
     return *this;
 }

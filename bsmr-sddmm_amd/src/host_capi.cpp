@@ -84,6 +84,11 @@ bsmr_pipeline* bsmr_pipeline_create(const bsmr_csr* m, float alpha, float delta,
     if (!m) return nullptr;
     return guarded([&]() -> bsmr_pipeline* {
         std::unique_ptr<bsmr_pipeline> p(new bsmr_pipeline);
+        struct DeviceScope {   // clustering, block size and plan of this pipeline all on `device`
+            int before = pipelineDevice();
+            explicit DeviceScope(int d) { if (d >= 0) setPipelineDevice(d); }
+            ~DeviceScope() { setPipelineDevice(before); }
+        } scope(device);
         if (row_mode == BSMR_ROWS_IDENTITY) {
             std::vector<UIN> rows;
             float t = 0;
@@ -231,7 +236,7 @@ int bsmr_host_sddmm(const bsmr_csr* m, uint32_t K, float alpha, float delta, int
             memcpy(log_buf, s.data(), n);
             log_buf[n] = 0;
         }
-        return logger.sddmmTime_ > 0 ? BSMR_OK : BSMR_ERR_HIP;
+        return logger.status_;
     }, BSMR_ERR_OOM);
 }
 

@@ -47,5 +47,7 @@ int main(int argc, char* argv[]) {
     sddmm(options, matrixA, matrixB, matrixP, logger);
 
     logger.printLogInformation();
-    return 0;
+    // a failed device call (no plan, unsupported K, out of memory, HIP error) is not a result: the record above
+    // carries [mi355x_status : n] and the exit code is non-zero
+    return logger.status_ == 0 ? 0 : 3;
 }

@@ -370,7 +370,7 @@ UIN calculateBlockSize(const sparseMatrix::CSR<float>& matrix, size_t freeDevice
 
 UIN calculateBlockSize(const sparseMatrix::CSR<float>& matrix) {
     size_t freeBytes = 0, totalBytes = 0;
-    if (bsmr_mem_info(0, &freeBytes, &totalBytes) != BSMR_OK || freeBytes == 0)
+    if (bsmr_mem_info(pipelineDevice(), &freeBytes, &totalBytes) != BSMR_OK || freeBytes == 0)
         freeBytes = static_cast<size_t>(288) << 30;  // MI355X HBM3E capacity
     return calculateBlockSize(matrix, freeBytes);
 }
@@ -552,9 +552,12 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
 // ---------------------------------------------------------------------------
 namespace {
 int g_clusteringDevice = -2;
+thread_local int g_pipelineDevice = 0;
 }
 void setClusteringDevice(int device) { g_clusteringDevice = device; }
 int clusteringDevice() { return g_clusteringDevice; }
+void setPipelineDevice(int device) { g_pipelineDevice = device < 0 ? 0 : device; }
+int pipelineDevice() { return g_pipelineDevice; }
 
 bool bsa_rowReordering_device(const sparseMatrix::CSR<float>& matrix, const float alpha, const UIN block_size,
                               int device, std::vector<UIN>& reorderedRows, int& num_clusters,

@@ -30,7 +30,7 @@ void sddmm(const Options& options, const Matrix<float>& matrixA, const Matrix<fl
     BSMR bsmr(options.similarityThresholdAlpha(), options.blockDensityThresholdDelta(), matrixP, 1);
     copyReorderingTimes(bsmr, logger);
 
-    RPHM rphm(matrixP, bsmr);
+    RPHM rphm(matrixP, bsmr, pipelineDevice());
     sddmm_gpu(matrixA, matrixB, rphm, matrixP, logger);
     evaluationReordering(matrixP, bsmr, logger);
 
@@ -71,7 +71,7 @@ void sddmm_testMode(const Options& options, sparseMatrix::CSR<float>& matrixP) {
         bsmr.rowReordering(alpha, matrixP);  // once per alpha; delta only moves the split
         for (const float delta : deltas) {
             bsmr.colReordering(delta, matrixP);
-            RPHM rphm(matrixP, bsmr);
+            RPHM rphm(matrixP, bsmr, pipelineDevice());
             for (const UIN k : Ks) {
                 Matrix<float> matrixA(matrixP.row(), k, row_major);
                 matrixA.makeData();

@@ -7,6 +7,7 @@
 #include <cstdio>
 
 #include "bsmr_hip.h"
+#include "BSMR.hpp"
 #include "devVector.hpp"
 
 namespace {
@@ -21,7 +22,7 @@ int sddmmComputeMode() { return g_computeMode; }
 
 std::string bsmrDeviceName() {
     char buf[256] = {0};
-    if (bsmr_device_name(0, buf, sizeof(buf)) != BSMR_OK) return "no device";
+    if (bsmr_device_name(pipelineDevice(), buf, sizeof(buf)) != BSMR_OK) return "no device";
     return buf;
 }
 
@@ -32,6 +33,7 @@ void sddmm_gpu(UIN M, UIN N, UIN K, const float* matrixA, const float* matrixB, 
     if (!rphm.plan()) {
         fprintf(stderr, "sddmm_gpu: RPHM has no device plan (status %d: %s)\n", rphm.planStatus(),
                 bsmr_strerror(rphm.planStatus()));
+        logger.status_ = rphm.planStatus() != BSMR_OK ? rphm.planStatus() : BSMR_ERR_INVALID_ARG;
         return;
     }
     bsmr_timing t{};
@@ -40,8 +42,10 @@ void sddmm_gpu(UIN M, UIN N, UIN K, const float* matrixA, const float* matrixB, 
                                     1, iters, &t);
     if (st != BSMR_OK) {
         fprintf(stderr, "sddmm_gpu: %s (%s)\n", bsmr_strerror(st), bsmr_last_hip_error());
+        logger.status_ = st;
         return;
     }
+    logger.status_ = BSMR_OK;
     bsmr_plan_stats s{};
     bsmr_plan_get_stats(rphm.plan(), &s);
     logger.gridDim_dense_ = Dim3{static_cast<unsigned>(s.dense_work_items), 1, 1};
@@ -62,11 +66,12 @@ void sddmm_gpu_k32(UIN M, UIN N, UIN K, const float* matrixA, const float* matri
 
 void sddmm_gpu(const Matrix<float>& matrixA, const Matrix<float>& matrixB, const RPHM& rphm,
                sparseMatrix::CSR<float>& matrixP, Logger& logger) {
-    dev::vector<float> A(matrixA.values());
-    dev::vector<float> B(matrixB.values());
-    dev::vector<float> P(matrixP.nnz(), 0, 0);
+    dev::vector<float> A(matrixA.values(), rphm.device());
+    dev::vector<float> B(matrixB.values(), rphm.device());
+    dev::vector<float> P(matrixP.nnz(), 0, rphm.device());
     if (!A.ok() || !B.ok() || !P.ok()) {
         fprintf(stderr, "sddmm_gpu: device allocation failed\n");
+        logger.status_ = BSMR_ERR_OOM;
         return;
     }
     sddmm_gpu(matrixP.row(), matrixP.col(), matrixA.col(), A.data(), B.data(), rphm, P.data(), logger);
@@ -86,10 +91,10 @@ void sddmm_gpu_batch(const UIN numBatch, const UIN M, const UIN N, const UIN K, 
     }
     // one untimed call (allocates the operand workspace), then the timed one
     int st = bsmr_sddmm_batch(rphm.plan(), K, matrixA, matrixB, matrixP, numBatch, g_computeMode, nullptr);
-    if (st == BSMR_OK) st = bsmr_device_synchronize(0);
+    if (st == BSMR_OK) st = bsmr_device_synchronize(rphm.device());
     const auto t0 = std::chrono::steady_clock::now();
     if (st == BSMR_OK) st = bsmr_sddmm_batch(rphm.plan(), K, matrixA, matrixB, matrixP, numBatch, g_computeMode, nullptr);
-    if (st == BSMR_OK) st = bsmr_device_synchronize(0);
+    if (st == BSMR_OK) st = bsmr_device_synchronize(rphm.device());
     if (st != BSMR_OK) {
         fprintf(stderr, "sddmm_gpu_batch: %s (%s)\n", bsmr_strerror(st), bsmr_last_hip_error());
         return;

@@ -8,6 +8,7 @@
  *   bsmr_plan_create     <- the twelve h2d() uploads at the end of RPHM::RPHM
  *                           (src/BSMR.cpp:252-264); takes the same host arrays
  *                           the reference's RPHM holds (include/BSMR.hpp:133-158)
+ *   bsmr_plan_create_ex  <- the same with every construction rule passed explicitly (bsmr_plan_options)
  *   bsmr_plan_destroy    <- ~RPHM / dev::vector destructors (include/devVector.cuh:54-126)
  *   bsmr_sddmm           <- sddmm_gpu(M,N,K, A_dev, B_dev, rphm, P_dev, logger) and
  *                           sddmm_gpu_k32(...) (include/sddmmKernel.cuh:25-39,
@@ -126,7 +127,58 @@ int bsmr_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int bsmr_dev_memset(void *dst_dev, int value, size_t bytes);
 int bsmr_device_synchronize(int device);
 
+/* Every rule of plan construction that is not a function of the RPHM arrays.  Zero-initialise, call
+ * bsmr_plan_options_default, change what is needed, pass to bsmr_plan_create_ex: a plan's layout, kernels and
+ * precision class are then a function of (desc, options) alone.  Fields named like the BSMR_<NAME> environment
+ * variables of bsmr_plan_options_from_env (the override used by tests, the CLI and bsmr_plan_create). */
+#define BSMR_ENGINE_STREAM  0  /* dense part: per-panel streaming kernels (denseStream / denseGroups), the default */
+#define BSMR_ENGINE_TILES   1  /* dense part: "tiles" format, H panels per wave-private B image (denseTiles)     */
+#define BSMR_ENGINE_SHARED  2  /* dense part: "tiles" format, B images shared by the 4 waves of a workgroup        */
+typedef struct bsmr_plan_options {
+    uint32_t struct_size;           /* sizeof(bsmr_plan_options) of the caller                                        */
+    int32_t  dense_engine;          /* BSMR_ENGINE_*                                                    [DENSE_ENGINE] */
+    /* which kernel computes an entry (the RPHM's own dense / sparse split is never changed) */
+    int32_t  fold_dense_below;      /* a dense part with fewer entries runs with the residue (32768)  [FOLD_DENSE_BELOW] */
+    int32_t  promote_average;       /* residue -> extra dense blocks when a panel averages this many
+                                       entries per 16 columns (16; 0 = never)                          [PROMOTE_AVERAGE] */
+    int32_t  promote_min_entries_k; /* ... plans without a dense part: only if this many thousand move (1000) [PROMOTE_MIN_ENTRIES_K] */
+    int32_t  promote_column_degree; /* ... only patterns with nnz / N at least this (32)          [PROMOTE_COLUMN_DEGREE] */
+    int32_t  promote_head;          /* ... leading blocks of other panels with this many entries (0 = none) [PROMOTE_HEAD] */
+    /* device format of the dense part, streaming engine */
+    int32_t  dense_group;           /* panels per group: 0 = both formats, chosen per call; 1, 2, 4        [DENSE_GROUP] */
+    int32_t  dense_blocks_per_item; /* 0 = from the plan's shape                                  [DENSE_BLOCKS_PER_WG] */
+    int32_t  stream_waves;          /* 1 or 4 waves per workgroup of denseStream (1)                       [STREAM_WAVES] */
+    int32_t  output_mode;           /* 0 = 16/32-bit offsets, 1 = 8-bit windows (default), 2 = windows staged in LDS [OUTPUT_MODE] */
+    int32_t  force_tile32;          /* 32-bit destination tiles                                            [FORCE_TILE32] */
+    int32_t  column_order;          /* blocks / items / residue in column order (1)                        [COLUMN_ORDER] */
+    int32_t  dense_stream;          /* streaming kernel for ungrouped formats (1)                          [DENSE_STREAM] */
+    int32_t  dense_batch;           /* blocks per LDS batch of denseGroups at K = 128 (0 = 4)               [DENSE_BATCH] */
+    /* device format of the dense part, tiles / shared engines */
+    int32_t  tile_group;            /* panels per group, 0 = cost model                                      [TILE_GROUP] */
+    int32_t  tile_blocks_per_item;  /* 0 = from the plan's shape                                            [TILE_BLOCKS] */
+    int32_t  tile_depth;            /* ring depth of denseTiles, 0 = default                                 [TILE_DEPTH] */
+    /* residue */
+    int32_t  sparse_entries_per_item; /* (256)                                                [SPARSE_ENTRIES_PER_WG] */
+    int32_t  sparse_lowp;           /* residue from the fp16/bf16 copies whenever they exist (1)             [SPARSE_LOWP] */
+    int32_t  sparse_lpe;            /* lanes per entry: 0 = tuned shape per K; 4, 8, 16                        [SPARSE_LPE] */
+    int32_t  free_residue;          /* 1: entries in global column order instead of per panel (0)          [FREE_RESIDUE] */
+    /* operand conversion */
+    int32_t  convert_in_kernel;     /* -1 = by size of the dense part; 0 / 1                           [CONVERT_IN_KERNEL] */
+    int32_t  convert_sliced;        /* B converted by the XCD that gathers it while it fits the L2s (1)  [CONVERT_SLICED] */
+    int32_t  b_only;                /* plans without a dense part may convert B alone (1)                         [B_ONLY] */
+    int32_t  b_only_work_m;         /* ... from this many million residue entries x K (100)                [B_ONLY_WORK_M] */
+    /* launch */
+    int32_t  overlap_streams;       /* dense and residue kernels of a hybrid plan on two streams joined by events:
+                                       -1 = when both parts are large enough, 0 = never, 1 = always      [OVERLAP_STREAMS] */
+} bsmr_plan_options;
+int bsmr_plan_options_default(bsmr_plan_options *opt);
+/* defaults, then every BSMR_<NAME> variable that is set */
+int bsmr_plan_options_from_env(bsmr_plan_options *opt);
+
+/* bsmr_plan_create = bsmr_plan_create_ex with bsmr_plan_options_from_env.  options == NULL: the defaults. */
 int bsmr_plan_create(bsmr_plan **out, int device, const bsmr_rphm_desc *desc);
+int bsmr_plan_create_ex(bsmr_plan **out, int device, const bsmr_rphm_desc *desc,
+                        const bsmr_plan_options *options);
 int bsmr_plan_destroy(bsmr_plan *plan);
 int bsmr_plan_get_stats(const bsmr_plan *plan, bsmr_plan_stats *out);
 /* Which dense format a call with inner dimension K uses (any out pointer may be NULL):

@@ -147,13 +147,15 @@ extern "C" int plancheck_tiles(const bsmr_rphm_desc* d, uint32_t H, uint32_t blo
         if (it && f.blockCols[(size_t)f.items[it - 1].first * 16] > f.blockCols[(size_t)item.first * 16]) return 3;  // column order
         for (uint32_t b = item.first; b < item.first + item.count; ++b) {
             if (blockSeen[b]++) return 4;
-            const uint32_t start = f.blockInfo[2 * (size_t)b], mask = f.blockInfo[2 * (size_t)b + 1] & 0xFFFFu;
-            const uint32_t n = f.blockInfo[2 * (size_t)b + 1] >> 16;
+            const uint32_t start = f.blockInfo[4 * (size_t)b], mask = f.blockInfo[4 * (size_t)b + 1] & 0xFFFFu;
+            const uint32_t n = f.blockInfo[4 * (size_t)b + 1] >> 16;
+            uint32_t quarter[4] = {0, 0, 0, 0};
             if (start % 4 || n == 0 || n > f.entryCap || (size_t)start + (n + 255) / 256 * 256 > f.entries.size()) return 5;
             uint32_t got = 0, last = 0;
             for (uint32_t e = 0; e < n; ++e) {
                 const uint32_t w = f.entries[start + e];
-                const uint32_t row = w & 127u, slot = (w >> 7) & 15u, off = w >> 11;
+                const uint32_t row = w & 255u, slot = (w >> 8) & 15u, off = w >> 12;
+                if (row < R) ++quarter[row / (4 * H)];
                 if (row >= R) return 6;
                 const uint32_t idx = f.itemRowBase[it * R + row] + off;
                 if (idx >= d->nnz || seen[idx]++) return 7;
@@ -165,6 +167,8 @@ extern "C" int plancheck_tiles(const bsmr_rphm_desc* d, uint32_t H, uint32_t blo
                 got |= 1u << (row / 16);
             }
             if (got != mask) return 11;
+            if ((quarter[0] | (quarter[1] << 16)) != f.blockInfo[4 * (size_t)b + 2] ||
+                (quarter[2] | (quarter[3] << 16)) != f.blockInfo[4 * (size_t)b + 3]) return 19;
             tiles += __builtin_popcount(mask);
             for (uint32_t c = 0; c < 16; ++c) {
                 if (c && f.blockCols[(size_t)b * 16 + c] != 0 && f.blockCols[(size_t)b * 16 + c] <= f.blockCols[(size_t)b * 16 + c - 1]) return 12;

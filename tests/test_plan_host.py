@@ -78,7 +78,7 @@ def tilecheck(engine):
     return run
 
 
-@pytest.mark.parametrize("H", [1, 2, 4, 8])
+@pytest.mark.parametrize("H", [1, 2, 4, 8, 16])
 @pytest.mark.parametrize("blocks_per_item", [1, 5, 32])
 def test_tiles_format_lists_every_dense_entry_once(tilecheck, H, blocks_per_item):
     """csrc/tile_format.hpp: the packed format, read the way the kernel reads it, reproduces the RPHM's dense part."""
@@ -96,10 +96,10 @@ def test_tiles_format_lists_every_dense_entry_once(tilecheck, H, blocks_per_item
 def test_tiles_format_cuts_blocks_at_the_entry_cap(tilecheck):
     """A block may hold at most 128 entries per panel of the group (the LDS room of the kernel): fuller blocks are
     cut at a column boundary."""
-    rows, cols = 128, 64
+    rows, cols = 256, 64
     ro = np.arange(rows + 1, dtype=np.uint32) * cols
     ci = np.tile(np.arange(cols, dtype=np.uint32), rows)          # a full matrix: 256 entries per 16x16 tile
-    for H in (1, 4, 8):
+    for H in (1, 4, 8, 16):
         rc, r = tilecheck(rows, cols, ro, ci, 0.3, 0.0, H, 4)
         assert rc == 0, (rc, r)
         assert r["entries"] == rows * cols and r["entry_cap"] <= 128 * H + 16 * H + 255

@@ -13,6 +13,7 @@ names = sys.argv[1:] or ["nips_k128_dense", "nips_k512_dense", "dlmc_k512_dense:
 groups = [int(x) for x in os.environ.get("LAB_GROUPS", "1,2,4,8").split(",")]
 blocks = [int(x) for x in os.environ.get("LAB_BLOCKS", "0").split(",")]
 depths = [int(x) for x in os.environ.get("LAB_DEPTHS", "0").split(",")]
+batches = [int(x) for x in os.environ.get("LAB_BATCHES", "0").split(",")]
 dev = torch.device("cuda:0")
 orc = Oracle()
 for name in names:
@@ -53,16 +54,19 @@ for name in names:
     run("tiles auto")
     for g in groups:
         for b in blocks:
-            for dep in depths:
+            for dep in [(d, nb) for d in depths for nb in batches]:
+                dep, nb = dep
+                if nb: os.environ["BSMR_TILE_BATCH"] = str(nb)
+                else: os.environ.pop("BSMR_TILE_BATCH", None)
                 os.environ["BSMR_TILE_GROUP"] = str(g)
                 if b: os.environ["BSMR_TILE_BLOCKS"] = str(b)
                 else: os.environ.pop("BSMR_TILE_BLOCKS", None)
                 if dep: os.environ["BSMR_TILE_DEPTH"] = str(dep)
                 else: os.environ.pop("BSMR_TILE_DEPTH", None)
                 try:
-                    run(f"tiles H={g} blocks={b or 'auto'} depth={dep or 'dflt'}")
+                    run(f"tiles H={g} blk={b or 'auto'} D={dep or 'dflt'} NB={nb or 'dflt'}")
                 except Exception as e:
                     print(f"tiles H={g} blocks={b}: {e}", flush=True)
-    os.environ.pop("BSMR_TILE_DEPTH", None)
+    os.environ.pop("BSMR_TILE_DEPTH", None); os.environ.pop("BSMR_TILE_BATCH", None)
     os.environ.pop("BSMR_TILE_GROUP", None); os.environ.pop("BSMR_TILE_BLOCKS", None)
     del pipe
