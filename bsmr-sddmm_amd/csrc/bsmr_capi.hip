@@ -760,59 +760,61 @@ int reserve(bsmr_plan* p, uint32_t K) {
 // which: bit 0 convert, bit 1 dense, bit 2 sparse
 int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, int mode, hipStream_t s,
               int which) {
-    int st = BSMR_OK;
+    const bool f16 = mode == BSMR_COMPUTE_F16;
+    const bool hasDense = p->fmt[0].numItems != 0 || p->hostDense.entries() != 0;
+    // what computes the dense part and the residue of this call
+    enum { kNone, kDense32, kDenseCvt, kDense16 } dense = kNone;
+    enum { kSparse32, kSparse16, kSparse16FromFp32A } sparse = kSparse32;
+    bool convertAll = false, convertB = false;
     if (mode == BSMR_COMPUTE_F32) {
-        if ((which & 2) && (st = launchDense32(p, K, A, B, P, s)) != BSMR_OK) return st;
+        dense = kDense32;
     } else if (convertsBOnly(p, K)) {
-        if (which & 1) {
-            st = mode == BSMR_COMPUTE_F16 ? launchConvert<0>(p, K, A, B, p->A16, p->B16, s, true)
-                                          : launchConvert<1>(p, K, A, B, p->A16, p->B16, s, true);
-            if (st != BSMR_OK) return st;
-        }
-        if (which & 4)
-            return mode == BSMR_COMPUTE_F16
-                       ? launchSparse16<0>(p, K, reinterpret_cast<const uint16_t*>(A), p->B16, P, s, true)
-                       : launchSparse16<1>(p, K, reinterpret_cast<const uint16_t*>(A), p->B16, P, s, true);
-        return BSMR_OK;
+        convertB = true;
+        sparse = kSparse16FromFp32A;
     } else if (p->convertInKernel) {
-        if (which & 2) {
-            st = mode == BSMR_COMPUTE_F16 ? launchDenseCvt<0>(p, K, A, B, P, s) : launchDenseCvt<1>(p, K, A, B, P, s);
-            if (st != BSMR_OK) return st;
-        }
+        dense = kDenseCvt;
     } else if (p->convertPass) {
-        if (which & 1) {
-            st = mode == BSMR_COMPUTE_F16 ? launchConvert<0>(p, K, A, B, p->A16, p->B16, s)
-                                          : launchConvert<1>(p, K, A, B, p->A16, p->B16, s);
-            if (st != BSMR_OK) return st;
-        }
-        if ((which & 6) == 6 && p->overlap && p->sparseLowp && p->fmt[0].numItems && p->numSparseItems) {
-            // fork: the residue kernel on the side stream behind the conversion, the dense kernel on the caller's;
-            // join: the caller's stream continues when both are done
-            BSMR_HIP(hipEventRecord(p->forkEvent, s));
-            BSMR_HIP(hipStreamWaitEvent(p->sideStream, p->forkEvent, 0));
-            st = mode == BSMR_COMPUTE_F16 ? launchSparse16<0>(p, K, p->A16, p->B16, P, p->sideStream)
-                                          : launchSparse16<1>(p, K, p->A16, p->B16, P, p->sideStream);
-            if (st != BSMR_OK) return st;
-            BSMR_HIP(hipEventRecord(p->joinEvent, p->sideStream));
-            st = mode == BSMR_COMPUTE_F16 ? launchDense16<0>(p, K, p->A16, p->B16, P, s)
-                                          : launchDense16<1>(p, K, p->A16, p->B16, P, s);
-            if (st != BSMR_OK) return st;
-            BSMR_HIP(hipStreamWaitEvent(s, p->joinEvent, 0));
-            return BSMR_OK;
-        }
-        if ((which & 2) && p->fmt[0].numItems) {
-            st = mode == BSMR_COMPUTE_F16 ? launchDense16<0>(p, K, p->A16, p->B16, P, s)
-                                          : launchDense16<1>(p, K, p->A16, p->B16, P, s);
-            if (st != BSMR_OK) return st;
-        }
-        if (p->sparseLowp) {
-            if (which & 4)
-                return mode == BSMR_COMPUTE_F16 ? launchSparse16<0>(p, K, p->A16, p->B16, P, s)
-                                                : launchSparse16<1>(p, K, p->A16, p->B16, P, s);
-            return BSMR_OK;
-        }
+        convertAll = true;
+        dense = kDense16;
+        if (p->sparseLowp) sparse = kSparse16;
     }
-    if ((which & 4) && (st = launchSparse(p, K, A, B, P, s)) != BSMR_OK) return st;
+    if (!hasDense) dense = kNone;
+    int st = BSMR_OK;
+    if ((which & 1) && (convertAll || convertB)) {
+        st = f16 ? launchConvert<0>(p, K, A, B, p->A16, p->B16, s, convertB) : launchConvert<1>(p, K, A, B, p->A16, p->B16, s, convertB);
+        if (st != BSMR_OK) return st;
+    }
+    auto runDense = [&](hipStream_t q) -> int {
+        switch (dense) {
+        case kDense32: return launchDense32(p, K, A, B, P, q);
+        case kDenseCvt: return f16 ? launchDenseCvt<0>(p, K, A, B, P, q) : launchDenseCvt<1>(p, K, A, B, P, q);
+        case kDense16: return f16 ? launchDense16<0>(p, K, p->A16, p->B16, P, q) : launchDense16<1>(p, K, p->A16, p->B16, P, q);
+        default: return BSMR_OK;
+        }
+    };
+    auto runSparse = [&](hipStream_t q) -> int {
+        switch (sparse) {
+        case kSparse16: return f16 ? launchSparse16<0>(p, K, p->A16, p->B16, P, q) : launchSparse16<1>(p, K, p->A16, p->B16, P, q);
+        case kSparse16FromFp32A:
+            return f16 ? launchSparse16<0>(p, K, reinterpret_cast<const uint16_t*>(A), p->B16, P, q, true)
+                       : launchSparse16<1>(p, K, reinterpret_cast<const uint16_t*>(A), p->B16, P, q, true);
+        default: return launchSparse(p, K, A, B, P, q);
+        }
+    };
+    if ((which & 6) == 6 && p->overlap && dense != kNone && p->numSparseItems) {
+        // hybrid call: the residue kernel on the side stream beside the dense kernel (the reference runs its two
+        // kernels on two streams, src/sddmmKernel.cu:2555-2559, 2576, 2618).  Fork behind the conversion, join on
+        // the caller's stream.  Entries are disjoint, operands read-only: no ordering between the two is needed.
+        BSMR_HIP(hipEventRecord(p->forkEvent, s));
+        BSMR_HIP(hipStreamWaitEvent(p->sideStream, p->forkEvent, 0));
+        if ((st = runSparse(p->sideStream)) != BSMR_OK) return st;
+        BSMR_HIP(hipEventRecord(p->joinEvent, p->sideStream));
+        if ((st = runDense(s)) != BSMR_OK) return st;
+        BSMR_HIP(hipStreamWaitEvent(s, p->joinEvent, 0));
+        return BSMR_OK;
+    }
+    if ((which & 2) && (st = runDense(s)) != BSMR_OK) return st;
+    if ((which & 4) && (st = runSparse(s)) != BSMR_OK) return st;
     return BSMR_OK;
 }
 
@@ -1161,7 +1163,7 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         if (st == BSMR_OK) st = upload(p->sparseItems, pk.sparseItems, p->indexBytes);
 
         // hybrid plans: side stream + events for the residue kernel beside the dense kernel
-        if (st == BSMR_OK && pk.numBlocks && pk.numSparseEntries && !p->convertInKernel &&
+        if (st == BSMR_OK && pk.numBlocks && pk.numSparseEntries &&
             (o.overlap_streams == 1 || (o.overlap_streams < 0 && pk.numDenseEntries >= 32768 && pk.numSparseEntries >= 32768))) {
             if (!hipOk(hipStreamCreateWithFlags(&p->sideStream, hipStreamNonBlocking), "hipStreamCreate") ||
                 !hipOk(hipEventCreateWithFlags(&p->forkEvent, hipEventDisableTiming), "hipEventCreate") ||

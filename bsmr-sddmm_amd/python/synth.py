@@ -97,6 +97,29 @@ def banded_mesh_like(n=121192, nnz=1362087, seed=2, empty_frac=0.18):
     return rows, cols, ro, ci
 
 
+def fem_node_blocks_like(n=121192, nnz=1362087, seed=2, block=16, block_frac=0.3):
+    """Second cop20k_A stand-in (BASELINE configs[2], "hybrid dense + sparse path"): the band of banded_mesh_like plus
+    the dense node blocks a finite-element matrix has - `block_frac` of the aligned groups of `block` consecutive
+    unknowns are fully coupled (strictly lower triangle of a block x block clique, 120 entries for 16).  At the
+    reference's default delta = 0.3 (>= 77 entries per 16 x 16 block) those cliques are dense blocks, the band
+    stays in the residue, and with 11 entries per column nothing is promoted: the DEFAULT plan runs both kernels.
+    (banded_mesh_like alone has no dense block at delta = 0.3.)  Same size and about the same nnz."""
+    rng = np.random.default_rng(seed + 1000)
+    groups = n // block
+    chosen = np.nonzero(rng.random(groups) < block_frac)[0]
+    tri = block * (block - 1) // 2
+    rows, cols, ro, ci = banded_mesh_like(n=n, nnz=max(nnz - tri * int(chosen.size), n), seed=seed)
+    li, lj = np.tril_indices(block, -1)
+    br = (chosen[:, None] * block + li[None, :]).ravel().astype(np.int64)
+    bc = (chosen[:, None] * block + lj[None, :]).ravel().astype(np.int64)
+    r0 = np.repeat(np.arange(n, dtype=np.int64), np.diff(ro.astype(np.int64)))
+    keys = np.unique(np.concatenate([r0 * n + ci.astype(np.int64), br * n + bc]))
+    r, c = keys // n, keys % n
+    ro2 = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(ro2, r + 1, 1)
+    return n, n, np.cumsum(ro2).astype(np.uint32), c.astype(np.uint32)
+
+
 def bernoulli(rows=4096, cols=4096, density=0.1, seed=4):
     """DLMC-style unstructured mask: i.i.d. Bernoulli(density)."""
     rng = np.random.default_rng(seed)

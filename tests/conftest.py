@@ -9,9 +9,6 @@ sys.path.insert(0, str(REPO / "bsmr-sddmm_amd" / "python"))
 import hostinfo  # noqa: E402
 
 hostinfo.limit_openmp_threads()   # before any OpenMP runtime starts: honour the container's CPU quota
-# Plans fold a dense part of < 32768 entries into the residue; the test matrices are that small, and the
-# dense kernels are what most tests are about.  test_small_dense_parts_are_folded covers the default.
-os.environ.setdefault("BSMR_FOLD_DENSE_BELOW", "0")
 
 import numpy as np  # noqa: E402
 import pytest  # noqa: E402
@@ -22,6 +19,29 @@ sys.path.insert(0, str(REPO))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "shipping_rules: the test builds its plans with the default bsmr_plan_options")
+
+
+@pytest.fixture(autouse=True)
+def plan_rules(request, monkeypatch):
+    """Which rules bsmr_plan_create applies (it reads the BSMR_* environment as its override, bsmr_plan_options_from_env):
+      "rphm"    - folding off (BSMR_FOLD_DENSE_BELOW=0): a dense part of any size runs on the dense kernels.  The
+                  test matrices are small, and the dense kernels are what most tests are about; the default for
+                  tests that do not ask otherwise.
+      "default" - the shipping defaults (fold < 32768 dense entries, promotion, B-only conversion, ...): tests
+                  marked `shipping_rules`, every BASELINE-size case, and the second leg of the tests parametrised
+                  with `both_rules`."""
+    mode = getattr(request, "param", None)
+    if mode is None:
+        mode = "default" if request.node.get_closest_marker("shipping_rules") else "rphm"
+    if mode == "rphm":
+        monkeypatch.setenv("BSMR_FOLD_DENSE_BELOW", "0")
+    else:
+        monkeypatch.delenv("BSMR_FOLD_DENSE_BELOW", raising=False)
+    return mode
+
+
+both_rules = pytest.mark.parametrize("plan_rules", ["rphm", "default"], indirect=True)
 
 
 def _ensure_built():

@@ -68,6 +68,28 @@ def test_argument_validation_without_gpu(engine):
     assert hip.bsmr_cluster_rows(0, 4, 4, None, None, 16, 0.3, None, None, None, None) == engine.ERR_INVALID_ARG
 
 
+def test_plan_options_defaults_and_environment_override(engine, monkeypatch):
+    """bsmr_plan_options: the defaults are the documented shipping rules; bsmr_plan_options_from_env - the one place
+    the environment is read for plan construction - overrides exactly the variables that are set."""
+    o = engine.plan_options()
+    assert o.struct_size == C.sizeof(engine.PlanOptions)
+    assert (o.dense_engine, o.fold_dense_below, o.promote_average, o.promote_column_degree) == (0, 32768, 16, 32)
+    assert (o.output_mode, o.column_order, o.sparse_lowp, o.convert_in_kernel, o.b_only, o.overlap_streams) == (1, 1, 1, -1, 1, -1)
+    for name in ("BSMR_FOLD_DENSE_BELOW", "BSMR_DENSE_ENGINE", "BSMR_TILE_GROUP", "BSMR_OVERLAP_STREAMS"):
+        monkeypatch.delenv(name, raising=False)
+    e = engine.PlanOptions()
+    assert engine.hip().bsmr_plan_options_from_env(C.byref(e)) == engine.OK
+    assert bytes(e) == bytes(o)
+    monkeypatch.setenv("BSMR_FOLD_DENSE_BELOW", "0")
+    monkeypatch.setenv("BSMR_DENSE_ENGINE", "shared")
+    monkeypatch.setenv("BSMR_TILE_GROUP", "8")
+    assert engine.hip().bsmr_plan_options_from_env(C.byref(e)) == engine.OK
+    assert (e.fold_dense_below, e.dense_engine, e.tile_group) == (0, engine.ENGINE_SHARED, 8)
+    assert e.promote_average == 16
+    assert engine.hip().bsmr_plan_options_default(None) == engine.ERR_INVALID_ARG
+    assert engine.hip().bsmr_plan_create_ex(None, 0, None, None) == engine.ERR_INVALID_ARG
+
+
 def test_no_device_is_an_error_code_not_a_crash(engine):
     if engine.device_count() > 0:
         pytest.skip("a GPU is visible: covered by the -m gpu tests")
@@ -101,7 +123,10 @@ def test_cli_contract(engine, tmp_path):
     synth.write_mtx(f, rows, cols, ro, ci)
     r = subprocess.run([str(exe), "-f", str(f), "-k", "32", "-a", "0.5", "-d", "0.1"], capture_output=True,
                        text=True, timeout=120)
-    # without a GPU the device plan cannot be created, but the record is still printed
+    # without a GPU the device plan cannot be created: the record is still printed, carries the status, and the
+    # exit code says that it is not a result
+    if engine.device_count() == 0:
+        assert r.returncode != 0 and "[mi355x_status : 2]" in r.stdout, (r.returncode, r.stdout)
     for key in ("[File : ", "[K : 32]", "[NNZ : 300]", "[bsmr_alpha : 0.50]", "[bsmr_delta : 0.10]", "[NumRowPanel : ",
                 "[bsmr_numDenseBlock : ", "[bsmr_gflops : "):
         assert key in r.stdout, (key, r.stdout, r.stderr)
