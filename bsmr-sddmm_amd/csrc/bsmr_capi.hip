@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1704,3 +1705,5 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
         return BSMR_ERR_INVALID_ARG;
     }
 }
+
+#include "sharded_capi.hpp"

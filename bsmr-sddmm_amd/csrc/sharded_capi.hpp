@@ -1,0 +1,223 @@
+// bsmr_sharded_*: one SDDMM over several GPUs of one node, driven from ONE process (include/bsmr_hip.h).
+//
+// Row panels are independent: the caller cuts the rows of S into contiguous ranges, builds the RPHM of
+// every range (host pipeline), and hands the ranges' RPHM arrays over.  Shard i lives on devices[i]: its plan, its rows
+// of A, a replica of B, its part of P.  A step launches bsmr_sddmm on every device (asynchronous launches from the
+// calling thread, one stream per device), then ONE gather-v of the compact fp32 outputs to devices[0] - RCCL send / recv
+// inside one group, created once per sharded object (ncclCommInitAll over the device list); ranges are contiguous in
+// S's row order, so the root's P is the concatenation of the shards' outputs and no permutation pass is needed.
+// Included at the end of bsmr_capi.hip (one translation unit).
+#pragma once
+
+#include <rccl/rccl.h>
+
+struct bsmr_sharded {
+    std::vector<int> devices;
+    std::vector<bsmr_plan*> plans;
+    std::vector<uint32_t> rowBegin;      // [n+1] global row of every shard's first row
+    std::vector<uint64_t> entryBegin;    // [n+1] offset of every shard's entries in P
+    uint32_t M = 0, N = 0;
+    std::vector<ncclComm_t> comms;       // one per device (single-process communicator clique), empty for n = 1
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> start, stop;
+    // device buffers of the last K served
+    uint32_t K = 0;
+    std::vector<float*> A, B, P;         // P[0] holds the whole result (root), P[i>0] the shard's part
+};
+
+namespace {
+
+void freeShardedBuffers(bsmr_sharded* s) {
+    for (size_t i = 0; i < s->devices.size(); ++i) {
+        if (hipSetDevice(s->devices[i]) != hipSuccess) (void)hipGetLastError();
+        if (i < s->A.size() && s->A[i]) (void)hipFree(s->A[i]);
+        if (i < s->B.size() && s->B[i]) (void)hipFree(s->B[i]);
+        if (i < s->P.size() && s->P[i]) (void)hipFree(s->P[i]);
+    }
+    s->A.clear();
+    s->B.clear();
+    s->P.clear();
+    s->K = 0;
+}
+
+#define BSMR_NCCL(call)                                                        \
+    do {                                                                       \
+        const ncclResult_t r_ = (call);                                        \
+        if (r_ != ncclSuccess) {                                               \
+            g_lastHipError = std::string(#call) + ": " + ncclGetErrorString(r_); \
+            return BSMR_ERR_HIP;                                               \
+        }                                                                      \
+    } while (0)
+
+// the gather-v of one step: peers send their part, the root receives each into its slot
+int shardedGather(bsmr_sharded* s) {
+    const size_t n = s->devices.size();
+    if (n == 1) return BSMR_OK;
+    BSMR_NCCL(ncclGroupStart());
+    for (size_t i = 1; i < n; ++i) {
+        const uint64_t count = s->entryBegin[i + 1] - s->entryBegin[i];
+        if (!count) continue;
+        BSMR_NCCL(ncclRecv(s->P[0] + s->entryBegin[i], count, ncclFloat, (int)i, s->comms[0], s->streams[0]));
+        BSMR_NCCL(ncclSend(s->P[i], count, ncclFloat, 0, s->comms[i], s->streams[i]));
+    }
+    BSMR_NCCL(ncclGroupEnd());
+    return BSMR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsmr_sharded_destroy(bsmr_sharded* s) {
+    if (!s) return BSMR_OK;
+    freeShardedBuffers(s);
+    for (size_t i = 0; i < s->devices.size(); ++i) {
+        if (hipSetDevice(s->devices[i]) != hipSuccess) (void)hipGetLastError();
+        if (i < s->comms.size() && s->comms[i]) (void)ncclCommDestroy(s->comms[i]);
+        if (i < s->streams.size() && s->streams[i]) (void)hipStreamDestroy(s->streams[i]);
+        if (i < s->start.size() && s->start[i]) (void)hipEventDestroy(s->start[i]);
+        if (i < s->stop.size() && s->stop[i]) (void)hipEventDestroy(s->stop[i]);
+        if (i < s->plans.size() && s->plans[i]) bsmr_plan_destroy(s->plans[i]);
+    }
+    delete s;
+    return BSMR_OK;
+}
+
+int bsmr_sharded_create(bsmr_sharded** out, const int* devices, uint32_t num_devices,
+                        const bsmr_rphm_desc* const* shard_descs, const uint32_t* row_begin,
+                        const bsmr_plan_options* options) {
+    if (!out || !devices || !shard_descs || !row_begin || num_devices == 0 || num_devices > 64) return BSMR_ERR_INVALID_ARG;
+    *out = nullptr;
+    for (uint32_t i = 0; i < num_devices; ++i) {
+        if (!shard_descs[i] || row_begin[i + 1] < row_begin[i] || shard_descs[i]->M != row_begin[i + 1] - row_begin[i] ||
+            shard_descs[i]->N != shard_descs[0]->N)
+            return BSMR_ERR_INVALID_ARG;
+        for (uint32_t j = 0; j < i; ++j)
+            if (devices[j] == devices[i]) return BSMR_ERR_INVALID_ARG;   // one shard per device
+    }
+    bsmr_sharded* s = new (std::nothrow) bsmr_sharded;
+    if (!s) return BSMR_ERR_OOM;
+    s->devices.assign(devices, devices + num_devices);
+    s->rowBegin.assign(row_begin, row_begin + num_devices + 1);
+    s->M = row_begin[num_devices] - row_begin[0];
+    s->N = shard_descs[0]->N;
+    s->entryBegin.assign(num_devices + 1, 0);
+    s->plans.assign(num_devices, nullptr);
+    s->streams.assign(num_devices, nullptr);
+    s->start.assign(num_devices, nullptr);
+    s->stop.assign(num_devices, nullptr);
+    int st = BSMR_OK;
+    for (uint32_t i = 0; i < num_devices && st == BSMR_OK; ++i) {
+        s->entryBegin[i + 1] = s->entryBegin[i] + shard_descs[i]->nnz;
+        st = bsmr_plan_create_ex(&s->plans[i], devices[i], shard_descs[i], options);
+        if (st != BSMR_OK) break;
+        if (!hipOk(hipStreamCreateWithFlags(&s->streams[i], hipStreamNonBlocking), "hipStreamCreate") ||
+            !hipOk(hipEventCreate(&s->start[i]), "hipEventCreate") || !hipOk(hipEventCreate(&s->stop[i]), "hipEventCreate"))
+            st = BSMR_ERR_HIP;
+    }
+    if (st == BSMR_OK && num_devices > 1) {
+        s->comms.assign(num_devices, nullptr);
+        const ncclResult_t r = ncclCommInitAll(s->comms.data(), (int)num_devices, s->devices.data());
+        if (r != ncclSuccess) {
+            g_lastHipError = std::string("ncclCommInitAll: ") + ncclGetErrorString(r);
+            st = BSMR_ERR_HIP;
+        }
+    }
+    if (st != BSMR_OK) {
+        bsmr_sharded_destroy(s);
+        return st;
+    }
+    *out = s;
+    return BSMR_OK;
+}
+
+int bsmr_sharded_num_entries(const bsmr_sharded* s, uint64_t* total, uint64_t* per_shard) {
+    if (!s || !total) return BSMR_ERR_INVALID_ARG;
+    *total = s->entryBegin.back();
+    if (per_shard)
+        for (size_t i = 0; i < s->devices.size(); ++i) per_shard[i] = s->entryBegin[i + 1] - s->entryBegin[i];
+    return BSMR_OK;
+}
+
+int bsmr_sharded_sddmm_host(bsmr_sharded* s, uint32_t K, const float* A_host, const float* B_host, float* P_host,
+                            int mode, int iters, bsmr_sharded_timing* timing) {
+    if (!s || !A_host || !B_host || !P_host) return BSMR_ERR_INVALID_ARG;
+    if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
+    if (iters <= 0) iters = 1;
+    const size_t n = s->devices.size();
+    const uint64_t nnz = s->entryBegin.back();
+    // operands: shard i's rows of A, all of B, its part of P (the root holds the whole P)
+    if (s->K != K) {
+        freeShardedBuffers(s);
+        s->A.assign(n, nullptr);
+        s->B.assign(n, nullptr);
+        s->P.assign(n, nullptr);
+        for (size_t i = 0; i < n; ++i) {
+            BSMR_HIP(hipSetDevice(s->devices[i]));
+            const size_t rows = s->rowBegin[i + 1] - s->rowBegin[i];
+            const uint64_t part = i == 0 ? nnz : s->entryBegin[i + 1] - s->entryBegin[i];
+            if (!hipOk(hipMalloc(reinterpret_cast<void**>(&s->A[i]), std::max<size_t>(rows * K * 4, 16)), "hipMalloc(A shard)") ||
+                !hipOk(hipMalloc(reinterpret_cast<void**>(&s->B[i]), std::max<size_t>((size_t)s->N * K * 4, 16)), "hipMalloc(B replica)") ||
+                !hipOk(hipMalloc(reinterpret_cast<void**>(&s->P[i]), std::max<size_t>(part * 4, 16)), "hipMalloc(P shard)"))
+                return BSMR_ERR_OOM;
+            int st = bsmr_plan_reserve(s->plans[i], K);
+            if (st != BSMR_OK) return st;
+        }
+        s->K = K;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        BSMR_HIP(hipSetDevice(s->devices[i]));
+        const size_t rows = s->rowBegin[i + 1] - s->rowBegin[i];
+        BSMR_HIP(hipMemcpyAsync(s->A[i], A_host + (size_t)(s->rowBegin[i] - s->rowBegin[0]) * K, rows * K * 4, hipMemcpyHostToDevice, s->streams[i]));
+        BSMR_HIP(hipMemcpyAsync(s->B[i], B_host, (size_t)s->N * K * 4, hipMemcpyHostToDevice, s->streams[i]));
+    }
+    for (size_t i = 0; i < n; ++i) {
+        BSMR_HIP(hipSetDevice(s->devices[i]));
+        BSMR_HIP(hipStreamSynchronize(s->streams[i]));
+    }
+    auto step = [&]() -> int {   // every device's SDDMM, then the gather
+        for (size_t i = 0; i < n; ++i) {
+            BSMR_HIP(hipSetDevice(s->devices[i]));
+            float* dst = i == 0 ? s->P[0] + s->entryBegin[0] : s->P[i];
+            const int st = bsmr_sddmm(s->plans[i], K, s->A[i], s->B[i], dst, mode, s->streams[i]);
+            if (st != BSMR_OK) return st;
+        }
+        return shardedGather(s);
+    };
+    int st = step();   // warm-up (workspaces, communicator channels)
+    for (size_t i = 0; i < n && st == BSMR_OK; ++i) {
+        BSMR_HIP(hipSetDevice(s->devices[i]));
+        BSMR_HIP(hipStreamSynchronize(s->streams[i]));
+    }
+    if (st != BSMR_OK) return st;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < n; ++i) {
+        BSMR_HIP(hipSetDevice(s->devices[i]));
+        BSMR_HIP(hipEventRecord(s->start[i], s->streams[i]));
+    }
+    for (int it = 0; it < iters && st == BSMR_OK; ++it) st = step();
+    if (st != BSMR_OK) return st;
+    float maxMs = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        BSMR_HIP(hipSetDevice(s->devices[i]));
+        BSMR_HIP(hipEventRecord(s->stop[i], s->streams[i]));
+    }
+    for (size_t i = 0; i < n; ++i) {
+        BSMR_HIP(hipSetDevice(s->devices[i]));
+        BSMR_HIP(hipEventSynchronize(s->stop[i]));
+        float ms = 0.0f;
+        BSMR_HIP(hipEventElapsedTime(&ms, s->start[i], s->stop[i]));
+        maxMs = std::max(maxMs, ms);
+    }
+    const double wallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    BSMR_HIP(hipSetDevice(s->devices[0]));
+    if (nnz) BSMR_HIP(hipMemcpy(P_host, s->P[0], nnz * 4, hipMemcpyDeviceToHost));
+    if (timing) {
+        timing->step_ms = maxMs / iters;
+        timing->wall_ms = (float)(wallMs / iters);
+        timing->num_devices = (uint32_t)n;
+    }
+    return BSMR_OK;
+}
+
+}  // extern "C"

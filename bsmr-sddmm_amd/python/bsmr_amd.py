@@ -81,6 +81,10 @@ class ClusterStats(C.Structure):
                 ("exact_similarities", C.c_uint32), ("threads_per_pair", C.c_uint32), ("table_bytes", C.c_uint64)]
 
 
+class ShardedTiming(C.Structure):
+    _fields_ = [("step_ms", C.c_float), ("wall_ms", C.c_float), ("num_devices", C.c_uint32)]
+
+
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("convert_ms", C.c_float), ("dense_ms", C.c_float),
                 ("sparse_ms", C.c_float)]
@@ -126,6 +130,12 @@ HIP_SYMBOLS = {
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "bsmr_sddmm_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "bsmr_sharded_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_uint32,
+                                      C.POINTER(C.POINTER(RphmDesc)), C.POINTER(C.c_uint32), C.POINTER(PlanOptions)]),
+    "bsmr_sharded_destroy": (C.c_int, [C.c_void_p]),
+    "bsmr_sharded_num_entries": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "bsmr_sharded_sddmm_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                          C.POINTER(ShardedTiming)]),
 }
 
 HOST_SYMBOLS = {
@@ -159,6 +169,10 @@ HOST_SYMBOLS = {
     "bsmr_host_check_data": (C.c_size_t, [C.c_size_t, C.c_void_p, C.c_void_p]),
     "bsmr_host_sddmm": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]),
+    "bsmr_host_sddmm_sharded": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int,
+                                          C.POINTER(C.c_int), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_float)]),
+    "bsmr_partition_rows_by_cost": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
 }
 
 
@@ -398,6 +412,25 @@ def sddmm_operator(csr: CSR, K: int, A, B, alpha=0.3, delta=0.3, mode=COMPUTE_F1
     _check(host().bsmr_host_sddmm(csr.handle, K, alpha, delta, mode, iters, _ptr(A), _ptr(B), _ptr(P),
                                   log, len(log)), "bsmr_host_sddmm")
     return P, log.value.decode()
+
+
+def partition_rows_by_cost(csr: CSR, world: int) -> list:
+    """partitionRowsByCost: world + 1 row boundaries of the C++ operator's cut"""
+    b = (C.c_uint32 * (world + 1))()
+    _check(host().bsmr_partition_rows_by_cost(csr.handle, world, b), "bsmr_partition_rows_by_cost")
+    return [int(x) for x in b]
+
+
+def sddmm_operator_sharded(csr: CSR, K: int, A, B, devices, alpha=0.3, delta=0.3, mode=COMPUTE_F16, iters=1):
+    """sddmm_multi_gpu on host operands -> (P, device ms per step)"""
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    B = np.ascontiguousarray(B, dtype=np.float32)
+    P = np.empty(csr.nnz, dtype=np.float32)
+    devs = (C.c_int * len(devices))(*devices)
+    ms = C.c_float(0)
+    _check(host().bsmr_host_sddmm_sharded(csr.handle, K, alpha, delta, mode, iters, devs, len(devices), _ptr(A), _ptr(B),
+                                          _ptr(P), C.byref(ms)), "bsmr_host_sddmm_sharded")
+    return P, ms.value
 
 
 # --- device entry points (pointers are integers, e.g. torch.Tensor.data_ptr()) ---

@@ -39,6 +39,28 @@ def partition_rows(row_offsets: np.ndarray, world: int):
     return bounds
 
 
+def row_costs(degrees: np.ndarray, c_entry: float = 1.0, c_panel: float = 24.0) -> np.ndarray:
+    """Cost model of SURVEY.md 8(e), per row and before a plan exists: a row's entries (each one a share of a dense
+    block's B gather and MFMA work, or one residue entry) plus its sixteenth of a 16-row panel's fixed work (A
+    fragments, block records) - so that ranges of many short rows do not look free."""
+    d = np.asarray(degrees, dtype=np.float64)
+    return c_entry * d + (c_panel / 16.0) * (d > 0)
+
+
+def partition_by_cost(costs: np.ndarray, world: int):
+    """Contiguous row ranges of nearly equal total cost: world+1 row boundaries, cut at multiples of 16 rows (a row
+    panel never straddles two ranks' plans for identity row order) except at the end."""
+    c = np.concatenate([[0.0], np.cumsum(np.asarray(costs, dtype=np.float64))])
+    rows = c.size - 1
+    bounds = [0]
+    for r in range(1, world):
+        cut = int(np.searchsorted(c, c[-1] * r / world, side="left"))
+        cut = min(max((cut + 8) // 16 * 16, bounds[-1]), rows)
+        bounds.append(cut)
+    bounds.append(rows)
+    return bounds
+
+
 def local_slice(rows, cols, ro, ci, r0, r1):
     """CSR of rows [r0, r1) with local row ids; also the slice's offset in the global P."""
     ro64 = ro.astype(np.int64)
@@ -108,9 +130,11 @@ def sharded_sddmm(dist, rank, world, ro, counts_offsets, compute, local_out, roo
 
 
 def run_sharded(eng, torch, dist, dev, rank, world, make_pattern, K, alpha, delta, mode, steps, warmup,
-                scaling="weak"):
+                scaling="weak", strong_rows=None):
     """bench.py's N > 1 path.  weak scaling: the job is `world` row-stacked patterns
-    (rank r generates and owns copy r); strong: one pattern cut into `world` ranges."""
+    (rank r generates and owns copy r); strong: one pattern cut into `world` ranges - with `strong_rows` =
+    (row costs of the whole pattern, make_rows(first_row, rows)) every rank builds ONLY its own rows, the
+    boundaries come from the cost partition."""
     import time
 
     if scaling == "weak":
@@ -122,6 +146,16 @@ def run_sharded(eng, torch, dist, dev, rank, world, make_pattern, K, alpha, delt
         counts = [int(c.item()) for c in allc]
         lrows, lnnz = rows, int(lci.size)
         total_rows = rows * world
+    elif strong_rows is not None:
+        costs, make_rows = strong_rows
+        b = partition_by_cost(costs, world)
+        lrows, cols, lro, lci = make_rows(b[rank], b[rank + 1] - b[rank])
+        lnnz = int(lci.size)
+        t = torch.tensor([lnnz], dtype=torch.int64, device=dev)
+        allc = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(allc, t)
+        counts = [int(c.item()) for c in allc]
+        total_rows = int(len(costs))
     else:
         rows, cols, ro, ci = make_pattern(0)
         b = partition_rows(ro, world)
@@ -178,7 +212,23 @@ def run_sharded(eng, torch, dist, dev, rank, world, make_pattern, K, alpha, delt
     # compute-only time (no gather), max over ranks
     kt = eng.sddmm_timed(pipe.plan, K, A.data_ptr(), B.data_ptr(), local_out.data_ptr(), mode, sh, 3, max(steps // 4, 5))
     ct = torch.tensor([kt["total_ms"]], dtype=torch.float64, device=dev)
+    per_rank = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(per_rank, ct.clone())
+    per_rank_ms = [float(x.item()) for x in per_rank]
     dist.all_reduce(ct, op=dist.ReduceOp.MAX)
+    # the gather alone: a few gather-v rounds with nothing to compute
+    for _ in range(2):
+        gather_to_root(dist, rank, world, local_outs[0], root_outs[0], offsets, counts)
+    torch.cuda.synchronize()
+    dist.barrier()
+    g0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        gather_to_root(dist, rank, world, local_outs[0], root_outs[0], offsets, counts)
+    torch.cuda.synchronize()
+    dist.barrier()
+    gt = torch.tensor([(time.perf_counter() - g0) / reps * 1e3], dtype=torch.float64, device=dev)
+    dist.all_reduce(gt, op=dist.ReduceOp.MAX)
     return {
         "metric": "SDDMM GFLOP/s", "value": round(2.0 * total_nnz * K / (ms * 1e6), 2), "unit": "GFLOP/s",
         "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
@@ -188,6 +238,10 @@ def run_sharded(eng, torch, dist, dev, rank, world, make_pattern, K, alpha, delt
                    "parallelism": f"row-range shards x{world}, B replicated, one RCCL gather-v to rank 0 per step"
                                   + (" (the gather of step i overlaps the compute of step i+1)" if pipelined else "")},
         "compute_only_ms_max": round(float(ct.item()), 5),
+        "compute_only_ms_per_rank": [round(x, 5) for x in per_rank_ms],
+        "compute_imbalance": round(max(per_rank_ms) / (sum(per_rank_ms) / len(per_rank_ms)), 4) if sum(per_rank_ms) > 0 else None,
+        "gather_only_ms": round(float(gt.item()), 5),
+        "nnz_per_rank": counts,
         "plan_build_s": round(plan_s, 3),
         # this rank's shard, for the caller's roofline (used on rank 0)
         "rank0": {"kernels_ms": kt, "pattern": (lrows, cols, lro, lci), "dense_tiles": pipe.dense_choice(K)["tiles"],

@@ -34,6 +34,33 @@ def _fit_counts(raw: np.ndarray, total: int, cap: int) -> np.ndarray:
     return c
 
 
+def _fit_counts_fast(raw: np.ndarray, total: int, cap: int) -> np.ndarray:
+    """_fit_counts for hundreds of thousands of rows: rescale the rows below the cap until the floor sum is within
+    one per row of `total`, then hand the remainder to the heaviest rows below the cap, one each (vectorised)."""
+    w = np.maximum(raw.astype(np.float64), 0)
+    c = np.zeros(w.size, dtype=np.int64)
+    free = np.ones(w.size, dtype=bool)
+    for _ in range(64):
+        left = total - int(c[~free].sum())
+        scale = left / max(w[free].sum(), 1e-300)
+        c[free] = np.floor(w[free] * scale).astype(np.int64)
+        over = free & (c > cap)
+        if not over.any():
+            break
+        c[over] = cap
+        free &= ~over
+    rem = total - int(c.sum())
+    while rem > 0:
+        order = np.argsort(-w, kind="stable")
+        order = order[c[order] < cap]
+        take = order[:rem]
+        if take.size == 0:
+            break
+        c[take] += 1
+        rem -= int(take.size)
+    return c
+
+
 def nips_like(rows=1500, cols=12419, nnz=746316, seed=1):
     """Bag-of-words shape (UCI NIPS dimensions): lognormal row lengths (mean ~498),
     Zipf(1.0) column popularity sampled without replacement inside a row."""
@@ -168,6 +195,36 @@ def reddit_shard_like(rows=29121, cols=232965, avg_degree=492, communities=41, i
         c = np.where(own, rng.integers(c0, c1, size=k), rng.integers(0, cols, size=k))
         per_row.append(np.unique(c))
     return _rows_to_csr(rows, cols, per_row)
+
+
+def reddit_like_degrees(n=232965, avg_degree=492, seed=3):
+    """Out-degree of every vertex of the reddit-like graph (BASELINE configs[3]: 232 965^2, nnz 114.6 M): power law,
+    mean `avg_degree`, capped at n / 4.  A function of (n, avg_degree, seed) alone, so every rank of a sharded run
+    computes the same sequence and can cut the rows by cost before any row exists."""
+    rng = np.random.default_rng(seed)
+    return _fit_counts_fast(rng.pareto(1.5, size=n) + 0.2, n * avg_degree, n // 4)
+
+
+def reddit_like_rows(first_row, rows, n=232965, avg_degree=492, communities=41, inside=0.8, seed=3, degrees=None):
+    """Rows [first_row, first_row + rows) of THE reddit-like graph over n vertices (reddit_like_degrees; `communities`
+    planted communities in contiguous id ranges, `inside` of a row's edges in its own).  Rows are generated in
+    globally aligned chunks of 1024 from a generator seeded by (seed, chunk), so any cut of the rows gives the same
+    graph: rank r of a sharded run builds only its own range.  Duplicates inside a row are dropped."""
+    deg = reddit_like_degrees(n, avg_degree, seed) if degrees is None else degrees
+    size = -(-n // communities)
+    per_row = []
+    last = min(first_row + rows, n)
+    for chunk in range(first_row // 1024, -(-last // 1024)):
+        rng = np.random.default_rng([seed, chunk])
+        for i in range(chunk * 1024, min((chunk + 1) * 1024, n)):
+            k = int(deg[i])
+            c0 = (i // size) * size
+            c1 = min(c0 + size, n)
+            own = rng.random(k) < inside
+            c = np.where(own, rng.integers(c0, c1, size=k), rng.integers(0, n, size=k))
+            if first_row <= i < last:
+                per_row.append(np.unique(c))
+    return _rows_to_csr(last - first_row, n, per_row)
 
 
 def random_pattern(rows, cols, nnz, seed, empty_rows=0):

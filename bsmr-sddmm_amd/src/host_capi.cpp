@@ -240,4 +240,37 @@ int bsmr_host_sddmm(const bsmr_csr* m, uint32_t K, float alpha, float delta, int
     }, BSMR_ERR_OOM);
 }
 
+int bsmr_partition_rows_by_cost(const bsmr_csr* m, uint32_t world, uint32_t* bounds) {
+    if (!m || !bounds || world == 0) return BSMR_ERR_INVALID_ARG;
+    return guarded([&]() -> int {
+        const std::vector<UIN> b = partitionRowsByCost(m->m, static_cast<int>(world));
+        std::copy(b.begin(), b.end(), bounds);
+        return BSMR_OK;
+    }, BSMR_ERR_OOM);
+}
+
+int bsmr_host_sddmm_sharded(const bsmr_csr* m, uint32_t K, float alpha, float delta, int compute_mode, int num_iterations,
+                            const int* devices, uint32_t num_devices, const float* A, const float* B, float* P,
+                            float* step_ms) {
+    if (!m || !A || !B || !P || !devices || num_devices == 0) return BSMR_ERR_INVALID_ARG;
+    if (K == 0 || K % 32) return BSMR_ERR_UNSUPPORTED_K;
+    return guarded([&]() -> int {
+        const std::string a = std::to_string(alpha), d = std::to_string(delta), k = std::to_string(K);
+        const char* argv[] = {"bsmr_host_sddmm_sharded", "-k", k.c_str(), "-a", a.c_str(), "-d", d.c_str()};
+        Options options(7, argv);
+        Matrix<float> ma(m->m.row(), K, row_major, A);
+        Matrix<float> mb(K, m->m.col(), col_major, B);
+        Logger logger;
+        if (num_iterations > 0) logger.numITER_ = num_iterations;
+        sparseMatrix::CSR<float> p(m->m);
+        const int before = sddmmComputeMode();
+        setSddmmComputeMode(compute_mode);
+        sddmm_multi_gpu(options, ma, mb, p, std::vector<int>(devices, devices + num_devices), logger);
+        setSddmmComputeMode(before);
+        memcpy(P, p.values().data(), p.values().size() * sizeof(float));
+        if (step_ms) *step_ms = logger.sddmmTime_;
+        return logger.status_;
+    }, BSMR_ERR_OOM);
+}
+
 }  // extern "C"

@@ -3,8 +3,12 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <fstream>
+#include <memory>
 #include <vector>
+
+#include "bsmr_hip.h"
 
 #include "BSMR.hpp"
 #include "checkData.hpp"
@@ -103,4 +107,89 @@ void sddmm_testMode(const Options& options, sparseMatrix::CSR<float>& matrixP) {
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// several GPUs of one node
+// ---------------------------------------------------------------------------
+std::vector<UIN> partitionRowsByCost(const sparseMatrix::CSR<float>& matrix, int world) {
+    // cost of a row = its entries + its sixteenth of a panel's fixed work (24 entry-equivalents per panel): the same
+    // model as python/shard.py row_costs / partition_by_cost
+    const UIN rows = matrix.row();
+    std::vector<double> prefix(static_cast<size_t>(rows) + 1, 0.0);
+    for (UIN r = 0; r < rows; ++r) {
+        const UIN d = matrix.rowOffsets()[r + 1] - matrix.rowOffsets()[r];
+        prefix[r + 1] = prefix[r] + static_cast<double>(d) + (d ? 24.0 / 16.0 : 0.0);
+    }
+    std::vector<UIN> bounds{0};
+    for (int r = 1; r < world; ++r) {
+        const double target = prefix[rows] * r / world;
+        UIN cut = static_cast<UIN>(std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin());
+        cut = std::min<UIN>(rows, std::max<UIN>((cut + 8) / 16 * 16, bounds.back()));
+        bounds.push_back(cut);
+    }
+    bounds.push_back(rows);
+    return bounds;
+}
+
+void sddmm_multi_gpu(const Options& options, const Matrix<float>& matrixA, const Matrix<float>& matrixB,
+                     sparseMatrix::CSR<float>& matrixP, const std::vector<int>& devices, Logger& logger) {
+    const int world = static_cast<int>(devices.size());
+    logger.status_ = BSMR_ERR_INVALID_ARG;
+    if (world <= 0) return;
+    const std::vector<UIN> bounds = partitionRowsByCost(matrixP, world);
+    const UIN K = matrixA.col();
+    std::vector<sparseMatrix::CSR<float>> slices;
+    std::vector<BSMR> bsmrs(world);
+    std::vector<std::unique_ptr<RPHM>> rphms(world);
+    std::vector<bsmr_rphm_desc> descs(world);
+    std::vector<const bsmr_rphm_desc*> descPtrs(world);
+    slices.reserve(world);
+    float reordering = 0.0f;
+    for (int i = 0; i < world; ++i) {
+        const UIN r0 = bounds[i], r1 = bounds[i + 1];
+        const UIN e0 = matrixP.rowOffsets()[r0], e1 = matrixP.rowOffsets()[r1];
+        std::vector<UIN> ro(static_cast<size_t>(r1 - r0) + 1), ci(matrixP.colIndices().begin() + e0, matrixP.colIndices().begin() + e1);
+        for (UIN r = r0; r <= r1; ++r) ro[r - r0] = matrixP.rowOffsets()[r] - e0;
+        slices.emplace_back(r1 - r0, matrixP.col(), e1 - e0, ro, ci);
+        struct DeviceScope {   // clustering of this slice on the slice's device
+            int before = pipelineDevice();
+            explicit DeviceScope(int d) { setPipelineDevice(d); }
+            ~DeviceScope() { setPipelineDevice(before); }
+        } scope(devices[i]);
+        bsmrs[i] = BSMR(options.similarityThresholdAlpha(), options.blockDensityThresholdDelta(), slices[i], 1);
+        rphms[i].reset(new RPHM(slices[i], bsmrs[i], -1));   // host arrays; the device side is bsmr_sharded_create
+        reordering = std::max(reordering, bsmrs[i].reorderingTime() + rphms[i]->time());
+        bsmr_rphm_desc& d = descs[i];
+        d = bsmr_rphm_desc{};
+        d.M = slices[i].row();
+        d.N = slices[i].col();
+        d.nnz = slices[i].nnz();
+        d.num_row_panels = static_cast<uint32_t>(bsmrs[i].numRowPanels());
+        d.num_nonzero_rows = static_cast<uint32_t>(bsmrs[i].reorderedRows().size());
+        d.reordered_rows = bsmrs[i].reorderedRows().data();
+        d.dense_cols = bsmrs[i].denseCols().data();
+        d.block_offsets = rphms[i]->blockOffsets().data();
+        d.block_values = rphms[i]->blockValues().data();
+        d.sparse_value_offsets = bsmrs[i].sparseValueOffsets().data();
+        d.sparse_values = rphms[i]->sparseValues().data();
+        d.sparse_relative_rows = rphms[i]->sparseRelativeRows().data();
+        d.sparse_col_indices = rphms[i]->sparseColIndices().data();
+        descPtrs[i] = &d;
+    }
+    logger.reorderingTime_ = reordering;
+    bsmr_plan_options opts;
+    bsmr_plan_options_from_env(&opts);
+    bsmr_sharded* sharded = nullptr;
+    int st = bsmr_sharded_create(&sharded, devices.data(), static_cast<uint32_t>(world), descPtrs.data(), bounds.data(), &opts);
+    if (st == BSMR_OK) {
+        bsmr_sharded_timing t{};
+        st = bsmr_sharded_sddmm_host(sharded, K, matrixA.data(), matrixB.data(), matrixP.setValues().data(), sddmmComputeMode(),
+                                     logger.numITER_ > 0 ? logger.numITER_ : 1, &t);
+        logger.sddmmTime_ = t.step_ms;
+    }
+    if (st != BSMR_OK) fprintf(stderr, "sddmm_multi_gpu: %s (%s)\n", bsmr_strerror(st), bsmr_last_hip_error());
+    bsmr_sharded_destroy(sharded);
+    logger.status_ = st;
+    logger.computeMode_ = sddmmComputeMode() == BSMR_COMPUTE_BF16 ? "bf16" : sddmmComputeMode() == BSMR_COMPUTE_F32 ? "f32" : "f16";
 }

@@ -27,6 +27,8 @@
  *                        <- no reference counterpart (the reference converts to
  *                           TF32 in registers); lets a caller that already holds
  *                           fp16/bf16 operands skip the per-call conversion
+ *   bsmr_sharded_*       <- no reference counterpart (the reference is single-GPU): row-range shards over the
+ *                           GPUs of one node, one RCCL gather-v of P per step
  *   bsmr_mem_info        <- cudaMemGetInfo in calculateBlockSize (src/rowReordering.cu:1010-1013)
  *   bsmr_dev_alloc / bsmr_dev_free / bsmr_memcpy_h2d / bsmr_memcpy_d2h / bsmr_dev_memset
  *                        <- dev::vector<T> ctor/dtor and h2d()/d2h() (include/devVector.cuh:54-126,
@@ -260,6 +262,29 @@ int bsmr_convert_operands(bsmr_plan *plan, uint32_t K, const float *A_dev, const
 int bsmr_sddmm_lowp(bsmr_plan *plan, uint32_t K, const void *A16_dev, const void *B16_dev,
                     const float *A_dev, const float *B_dev, float *P_dev, int compute_mode,
                     void *stream);
+
+/* ---- one SDDMM over several GPUs of one node, from one process (the reference is single-GPU) ----
+ * Row panels are independent, so the rows of S are cut into contiguous ranges (the caller's cost partition) and
+ * every range is a problem of its own: shard_descs[i] is the RPHM of rows [row_begin[i], row_begin[i+1]) with LOCAL
+ * row ids (built by the host pipeline on that slice), devices[i] the GPU it lives on.  A step runs bsmr_sddmm on
+ * every device and gathers the compact outputs to devices[0] with one RCCL send/recv group (communicators are
+ * created once, in bsmr_sharded_create); P in S's CSR order is the concatenation of the shards' outputs. */
+typedef struct bsmr_sharded bsmr_sharded;
+typedef struct bsmr_sharded_timing {
+    float    step_ms;      /* device time of one step (SDDMM on every device + gather), max over devices */
+    float    wall_ms;      /* host wall time of one step                                                  */
+    uint32_t num_devices;
+} bsmr_sharded_timing;
+int bsmr_sharded_create(bsmr_sharded **out, const int *devices, uint32_t num_devices,
+                        const bsmr_rphm_desc *const *shard_descs, const uint32_t *row_begin,
+                        const bsmr_plan_options *options);
+int bsmr_sharded_destroy(bsmr_sharded *s);
+/* total stored entries (length of P) and, if per_shard != NULL, every shard's share */
+int bsmr_sharded_num_entries(const bsmr_sharded *s, uint64_t *total, uint64_t *per_shard);
+/* Host operands in (A: all rows, row-major M x K; B: K x N column-major), host P out (S's CSR order): uploads every
+ * shard's rows of A and a replica of B, one warm-up step, `iters` timed steps, download from the root. */
+int bsmr_sharded_sddmm_host(bsmr_sharded *s, uint32_t K, const float *A_host, const float *B_host, float *P_host,
+                            int compute_mode, int iters, bsmr_sharded_timing *timing);
 
 /* Host operands in, host P out (upload, `iters` timed repetitions after one
  * warm-up, download).  ms_per_iter may be NULL. */

@@ -118,6 +118,15 @@ int bsmr_host_sddmm(const bsmr_csr *m, uint32_t K, float alpha, float delta, int
                     int num_iterations, const float *A, const float *B, float *P,
                     char *log_buf, size_t log_buf_len);
 
+/* sddmm_multi_gpu (bsmr-sddmm_amd/include/sddmm.hpp; no reference counterpart - the reference is single-GPU): the
+ * operator over `num_devices` GPUs of one node from one process - rows cut by cost, the whole pipeline per slice,
+ * bsmr_sharded_* underneath (one RCCL gather-v of P per step).  step_ms (may be NULL) receives the device time of one
+ * step.  bsmr_partition_rows_by_cost writes the world + 1 row boundaries of that cut. */
+int bsmr_host_sddmm_sharded(const bsmr_csr *m, uint32_t K, float alpha, float delta, int compute_mode,
+                            int num_iterations, const int *devices, uint32_t num_devices, const float *A,
+                            const float *B, float *P, float *step_ms);
+int bsmr_partition_rows_by_cost(const bsmr_csr *m, uint32_t world, uint32_t *bounds);
+
 #ifdef __cplusplus
 }
 #endif

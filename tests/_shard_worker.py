@@ -100,6 +100,39 @@ def main():
                 want = oracle.sddmm_cpu(rr, rc, K, rro, rci, eng.make_data(rr * K, 300 + r), B) * np.float32(stepno + 1)
                 seg = got[offsets[r]:offsets[r] + counts[r]]
                 assert np.array_equal(seg.view(np.uint32), want.view(np.uint32)), f"pipelined step {stepno}, shard {r}"
+    # ---- strong scaling by cost (bench.py --gpus N default): every rank builds ONLY its own rows of one graph,
+    #      the row ranges come from the cost partition of the degree sequence, which every rank can compute ----
+    n, Kc = 2600, 32
+    deg = synth.reddit_like_degrees(n=n, avg_degree=24)
+    bounds = shard.partition_by_cost(shard.row_costs(deg), world)
+    assert bounds[0] == 0 and bounds[-1] == n and all(a <= b for a, b in zip(bounds, bounds[1:]))
+    assert all(b % 16 == 0 for b in bounds[1:-1])
+    lrows, lcols, lro, lci = synth.reddit_like_rows(bounds[rank], bounds[rank + 1] - bounds[rank], n=n, avg_degree=24,
+                                                    communities=5, degrees=deg)
+    csr = eng.CSR.from_arrays(lrows, lcols, lro, lci)
+    pipe = eng.Pipeline(csr, alpha=0.3, delta=0.3, device=-1)       # the whole host pipeline on the rank's own rows
+    assert pipe.check()
+    mine = torch.tensor([lci.size], dtype=torch.int64)
+    allc = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allc, mine)
+    counts = [int(c.item()) for c in allc]
+    offsets = [int(x) for x in np.cumsum([0] + counts[:-1])]
+    Bc = eng.make_data(n * Kc, 41)
+    Ac = eng.make_data(n * Kc, 40).reshape(n, Kc)[bounds[rank]:bounds[rank + 1]].ravel().copy()
+    root_out = torch.zeros(sum(counts) if rank == 0 else 1, dtype=torch.float32)
+    local_out = root_out[:counts[0]] if rank == 0 else torch.zeros(counts[rank], dtype=torch.float32)
+
+    def compute_cost():
+        local_out.copy_(torch.from_numpy(oracle.sddmm_cpu(lrows, lcols, Kc, lro, lci, Ac, Bc)))
+
+    shard.sharded_sddmm(dist, rank, world, None, (offsets, counts), compute_cost, local_out, root_out)
+    if rank == 0:
+        fr, fc, fro, fci = synth.reddit_like_rows(0, n, n=n, avg_degree=24, communities=5, degrees=deg)
+        assert fci.size == sum(counts)
+        want = oracle.sddmm_cpu(fr, fc, Kc, fro, fci, eng.make_data(n * Kc, 40), Bc)
+        assert np.array_equal(root_out.numpy().view(np.uint32), want.view(np.uint32)), "strong by cost: gathered P differs"
+        per = [int(deg[bounds[r]:bounds[r + 1]].sum()) for r in range(world)]
+        assert max(per) - min(per) <= 0.1 * max(per), per
         print("SHARD_OK", world)
     dist.barrier()
     dist.destroy_process_group()

@@ -779,3 +779,24 @@ def test_two_plans_on_two_devices_in_one_process(engine, oracle):
             assert bad == 0, f"device {d}"
     finally:
         del os.environ["BSMR_OUTPUT_MODE"], os.environ["BSMR_DENSE_GROUP"]
+
+
+def test_sharded_operator_from_one_process(engine, oracle):
+    """bsmr_sharded_* / sddmm_multi_gpu: row ranges cut by cost, the whole pipeline per range, every range on its own
+    device, one RCCL gather-v to the first device; P in S's CSR order is the concatenation of the shards' outputs.
+    With one visible GPU the one-device path runs (no communicator); with more, every GPU gets a shard."""
+    rows, cols, ro, ci = synth.reddit_like_rows(0, 6000, n=6000, avg_degree=60, communities=8)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    K = 128
+    A, B = engine.make_data(rows * K, 5489), engine.make_data(cols * K, 5490)
+    want = oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B)
+    n = min(torch.cuda.device_count(), 4)
+    for devices in ([0], list(range(n))) if n > 1 else ([0],):
+        got, ms = engine.sddmm_operator_sharded(csr, K, A, B, devices, alpha=0.3, delta=0.3, iters=3)
+        bad, first = oracle.check_data(want, got)
+        assert bad == 0 and ms > 0, (devices, bad, first)
+    # a device listed twice, no device, an absent device: status codes
+    with pytest.raises(engine.BsmrError):
+        engine.sddmm_operator_sharded(csr, K, A, B, [0, 0])
+    with pytest.raises(engine.BsmrError):
+        engine.sddmm_operator_sharded(csr, K, A, B, [99])

@@ -35,3 +35,36 @@ def test_partition_rows_balances_nnz():
     # degenerate: more ranks than rows with entries
     b = shard.partition_rows(np.array([0, 5, 5, 5], np.uint32), 4)
     assert b[0] == 0 and b[-1] == 3 and all(x <= y for x, y in zip(b, b[1:]))
+
+
+def test_partition_by_cost_balances_the_cost_model():
+    """shard.partition_by_cost: contiguous ranges of equal cost = entries + a panel share per non-empty
+    row, cut at row-panel boundaries; empty-row stretches do not attract a rank."""
+    import shard
+    rng = np.random.default_rng(2)
+    deg = np.concatenate([rng.integers(200, 400, size=4000), np.zeros(6000, np.int64), rng.integers(1, 4, size=22000)])
+    costs = shard.row_costs(deg)
+    for world in (2, 4, 8):
+        b = shard.partition_by_cost(costs, world)
+        assert b[0] == 0 and b[-1] == deg.size and all(x <= y for x, y in zip(b, b[1:]))
+        assert all(x % 16 == 0 for x in b[1:-1])
+        per = [float(costs[b[i]:b[i + 1]].sum()) for i in range(world)]
+        assert max(per) <= 1.02 * (sum(per) / world) + 16 * float(costs.max())
+    # by nnz alone the 22 000 short rows (3 entries each, one panel share each) would all land on the last rank
+    b_nnz = shard.partition_rows(np.concatenate([[0], np.cumsum(deg)]).astype(np.uint32), 8)
+    b_cost = shard.partition_by_cost(costs, 8)
+    assert (b_cost[-1] - b_cost[-2]) < (b_nnz[-1] - b_nnz[-2])
+    # the graph generator gives the same rows whatever the cut
+    a = synth.reddit_like_rows(500, 700, n=3000, avg_degree=10, communities=4)
+    full = synth.reddit_like_rows(0, 3000, n=3000, avg_degree=10, communities=4)
+    assert np.array_equal(a[3], full[3][full[2][500]:full[2][1200]])
+
+
+def test_cpp_cost_partition_matches_the_python_one(engine):
+    """partitionRowsByCost (the C++ operator sddmm_multi_gpu) and shard.partition_by_cost (bench.py) cut the same way."""
+    import shard
+    rows, cols, ro, ci = synth.reddit_like_rows(0, 3000, n=3000, avg_degree=30, communities=6)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    deg = np.diff(ro.astype(np.int64))
+    for world in (1, 2, 3, 8):
+        assert engine.partition_rows_by_cost(csr, world) == shard.partition_by_cost(shard.row_costs(deg), world)
