@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <set>
@@ -1165,7 +1166,10 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
 
         // hybrid plans: side stream + events for the residue kernel beside the dense kernel
         if (st == BSMR_OK && pk.numBlocks && pk.numSparseEntries &&
-            (o.overlap_streams == 1 || (o.overlap_streams < 0 && pk.numDenseEntries >= 32768 && pk.numSparseEntries >= 32768))) {
+            (o.overlap_streams == 1 || (o.overlap_streams < 0 && pk.numDenseEntries >= (4u << 20) && pk.numSparseEntries >= (4u << 20)))) {
+            // (measured on MI355X: the fork / join through two events costs 7-15 us per call - cop20k-like with node
+            // blocks, K=128: 51.3 us serial, 66.1 forked; 4096^2 delta=0.1 as the RPHM splits it, K=512: 70.8 vs 77.8 -
+            // so by default only plans whose two kernels both run for ~100 us or more fork)
             if (!hipOk(hipStreamCreateWithFlags(&p->sideStream, hipStreamNonBlocking), "hipStreamCreate") ||
                 !hipOk(hipEventCreateWithFlags(&p->forkEvent, hipEventDisableTiming), "hipEventCreate") ||
                 !hipOk(hipEventCreateWithFlags(&p->joinEvent, hipEventDisableTiming), "hipEventCreate"))
@@ -1707,3 +1711,4 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
 }
 
 #include "sharded_capi.hpp"
+#include "colreorder_capi.hpp"

@@ -9,7 +9,45 @@
 // Included at the end of bsmr_capi.hip (one translation unit).
 #pragma once
 
+#include <dlfcn.h>
 #include <rccl/rccl.h>
+
+// RCCL is bound at run time, when a sharded object over more than one device is created: libbsmr_hip.so carries no
+// load-time dependency on librccl (a process that also loads PyTorch must end up with ONE copy of it - whichever
+// librccl.so.1 is already in the process is the one dlopen returns).
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) commInitAll = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclGroupStart) groupStart = nullptr;
+    decltype(&ncclGroupEnd) groupEnd = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGetErrorString) errorString = nullptr;
+    bool ok() const { return commInitAll && commDestroy && groupStart && groupEnd && send && recv && errorString; }
+};
+RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (a.lib) {
+            a.commInitAll = reinterpret_cast<decltype(a.commInitAll)>(dlsym(a.lib, "ncclCommInitAll"));
+            a.commDestroy = reinterpret_cast<decltype(a.commDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+            a.groupStart = reinterpret_cast<decltype(a.groupStart)>(dlsym(a.lib, "ncclGroupStart"));
+            a.groupEnd = reinterpret_cast<decltype(a.groupEnd)>(dlsym(a.lib, "ncclGroupEnd"));
+            a.send = reinterpret_cast<decltype(a.send)>(dlsym(a.lib, "ncclSend"));
+            a.recv = reinterpret_cast<decltype(a.recv)>(dlsym(a.lib, "ncclRecv"));
+            a.errorString = reinterpret_cast<decltype(a.errorString)>(dlsym(a.lib, "ncclGetErrorString"));
+        }
+        return a;
+    }();
+    return api;
+}
+}  // namespace
 
 struct bsmr_sharded {
     std::vector<int> devices;
@@ -44,7 +82,7 @@ void freeShardedBuffers(bsmr_sharded* s) {
     do {                                                                       \
         const ncclResult_t r_ = (call);                                        \
         if (r_ != ncclSuccess) {                                               \
-            g_lastHipError = std::string(#call) + ": " + ncclGetErrorString(r_); \
+            g_lastHipError = std::string(#call) + ": " + rccl().errorString(r_); \
             return BSMR_ERR_HIP;                                               \
         }                                                                      \
     } while (0)
@@ -53,14 +91,14 @@ void freeShardedBuffers(bsmr_sharded* s) {
 int shardedGather(bsmr_sharded* s) {
     const size_t n = s->devices.size();
     if (n == 1) return BSMR_OK;
-    BSMR_NCCL(ncclGroupStart());
+    BSMR_NCCL(rccl().groupStart());
     for (size_t i = 1; i < n; ++i) {
         const uint64_t count = s->entryBegin[i + 1] - s->entryBegin[i];
         if (!count) continue;
-        BSMR_NCCL(ncclRecv(s->P[0] + s->entryBegin[i], count, ncclFloat, (int)i, s->comms[0], s->streams[0]));
-        BSMR_NCCL(ncclSend(s->P[i], count, ncclFloat, 0, s->comms[i], s->streams[i]));
+        BSMR_NCCL(rccl().recv(s->P[0] + s->entryBegin[i], count, ncclFloat, (int)i, s->comms[0], s->streams[0]));
+        BSMR_NCCL(rccl().send(s->P[i], count, ncclFloat, 0, s->comms[i], s->streams[i]));
     }
-    BSMR_NCCL(ncclGroupEnd());
+    BSMR_NCCL(rccl().groupEnd());
     return BSMR_OK;
 }
 
@@ -73,7 +111,7 @@ int bsmr_sharded_destroy(bsmr_sharded* s) {
     freeShardedBuffers(s);
     for (size_t i = 0; i < s->devices.size(); ++i) {
         if (hipSetDevice(s->devices[i]) != hipSuccess) (void)hipGetLastError();
-        if (i < s->comms.size() && s->comms[i]) (void)ncclCommDestroy(s->comms[i]);
+        if (i < s->comms.size() && s->comms[i]) (void)rccl().commDestroy(s->comms[i]);
         if (i < s->streams.size() && s->streams[i]) (void)hipStreamDestroy(s->streams[i]);
         if (i < s->start.size() && s->start[i]) (void)hipEventDestroy(s->start[i]);
         if (i < s->stop.size() && s->stop[i]) (void)hipEventDestroy(s->stop[i]);
@@ -116,11 +154,16 @@ int bsmr_sharded_create(bsmr_sharded** out, const int* devices, uint32_t num_dev
             st = BSMR_ERR_HIP;
     }
     if (st == BSMR_OK && num_devices > 1) {
-        s->comms.assign(num_devices, nullptr);
-        const ncclResult_t r = ncclCommInitAll(s->comms.data(), (int)num_devices, s->devices.data());
-        if (r != ncclSuccess) {
-            g_lastHipError = std::string("ncclCommInitAll: ") + ncclGetErrorString(r);
+        if (!rccl().ok()) {
+            g_lastHipError = "librccl.so.1 could not be loaded (needed for more than one device)";
             st = BSMR_ERR_HIP;
+        } else {
+            s->comms.assign(num_devices, nullptr);
+            const ncclResult_t r = rccl().commInitAll(s->comms.data(), (int)num_devices, s->devices.data());
+            if (r != ncclSuccess) {
+                g_lastHipError = std::string("ncclCommInitAll: ") + rccl().errorString(r);
+                st = BSMR_ERR_HIP;
+            }
         }
     }
     if (st != BSMR_OK) {

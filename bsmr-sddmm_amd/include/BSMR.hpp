@@ -57,7 +57,17 @@ public:
     float colReorderingTime() const { return colReorderingTime_; }
     float reorderingTime() const { return rowReorderingTime_ + colReorderingTime_; }
 
+    // Index arrays of the RPHM when the column reordering ran on the device (bsmr_col_reorder computes them in the
+    // same pass; RPHM::RPHM then takes them instead of rebuilding them on the host).  Empty otherwise.
+    struct DeviceRphmArrays {
+        bool valid = false;
+        std::vector<UIN> blockOffsets, blockValues, sparseValues, sparseRelativeRows, sparseColIndices;
+        float deviceMs = 0.0f;
+    };
+    const DeviceRphmArrays& deviceRphm() const { return deviceRphm_; }
+
 private:
+    DeviceRphmArrays deviceRphm_;
     int numRowPanels_ = 0;
     std::vector<UIN> reorderedRows_;
     std::vector<UIN> denseCols_;
@@ -164,8 +174,9 @@ UIN calculateBlockSize(const sparseMatrix::CSR<float>& matrix, size_t freeDevice
 // Where BSMR::rowReordering runs the clustering.  The reference always uses the GPU
 // (bsa_rowReordering_gpu); both implementations here give the same row order and cluster
 // count, so this is a matter of speed only.
-//   -2 (default): device 0 when one is present and the rows are long enough for the dense
-//                 device scan to win (>= 32 stored entries per non-empty row on average;
+//   -2 (default): the pipeline's device when one is present, the rows are long enough for the dense
+//                 device scan to win (>= 32 stored entries per non-empty row on average) and there
+//                 are at least 4096 of them (
 //                 measured on MI355X: mycielskian15 0.33 s on the device against 5-12 s on
 //                 the host, wathen100 0.79 s against 0.24 s); environment BSMR_CLUSTER =
 //                 host | device overrides the rule
@@ -178,6 +189,15 @@ int clusteringDevice();
 // pipeline's device, so that no rank clusters on, allocates on or leaves the process on GPU 0.
 void setPipelineDevice(int device);
 int pipelineDevice();
+// Where BSMR::colReordering runs: -2 (default) = on the pipeline's device when one is present and S stores at least
+// 4 M entries (BSMR_COLREORDER = host | device overrides), -1 = host, >= 0 = that device.  Both give the same arrays.
+void setColReorderingDevice(int device);
+int colReorderingDevice();
+bool colReordering_device(const sparseMatrix::CSR<float>& matrix, const std::vector<UIN>& reorderedRows,
+                          const float blockDensityThreshold, int device, std::vector<UIN>& denseCols,
+                          std::vector<UIN>& denseColOffsets, std::vector<UIN>& sparseCols,
+                          std::vector<UIN>& sparseColOffsets, std::vector<UIN>& sparseDataOffsets,
+                          BSMR::DeviceRphmArrays& rphmArrays, float& time);
 
 // bsa_rowReordering_gpu of the reference (src/rowReordering.cu:1027-1095) on the MI355X:
 // csrc/cluster_kernels.hpp through bsmr_cluster_rows.  Returns false when the device path is

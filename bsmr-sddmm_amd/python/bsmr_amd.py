@@ -81,6 +81,11 @@ class ClusterStats(C.Structure):
                 ("exact_similarities", C.c_uint32), ("threads_per_pair", C.c_uint32), ("table_bytes", C.c_uint64)]
 
 
+class ColReorderSizes(C.Structure):
+    _fields_ = [("num_row_panels", C.c_uint32), ("num_dense_cols", C.c_uint64), ("num_sparse_cols", C.c_uint64),
+                ("num_blocks", C.c_uint64), ("num_sparse_entries", C.c_uint64), ("elapsed_ms", C.c_float)]
+
+
 class ShardedTiming(C.Structure):
     _fields_ = [("step_ms", C.c_float), ("wall_ms", C.c_float), ("num_devices", C.c_uint32)]
 
@@ -130,6 +135,11 @@ HIP_SYMBOLS = {
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "bsmr_sddmm_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "bsmr_col_reorder": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_uint32, C.c_float]),
+    "bsmr_col_reorder_sizes": (C.c_int, [C.c_void_p, C.POINTER(ColReorderSizes)]),
+    "bsmr_col_reorder_fetch": (C.c_int, [C.c_void_p] + [C.c_void_p] * 10),
+    "bsmr_col_reorder_free": (C.c_int, [C.c_void_p]),
     "bsmr_sharded_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_uint32,
                                       C.POINTER(C.POINTER(RphmDesc)), C.POINTER(C.c_uint32), C.POINTER(PlanOptions)]),
     "bsmr_sharded_destroy": (C.c_int, [C.c_void_p]),
@@ -412,6 +422,31 @@ def sddmm_operator(csr: CSR, K: int, A, B, alpha=0.3, delta=0.3, mode=COMPUTE_F1
     _check(host().bsmr_host_sddmm(csr.handle, K, alpha, delta, mode, iters, _ptr(A), _ptr(B), _ptr(P),
                                   log, len(log)), "bsmr_host_sddmm")
     return P, log.value.decode()
+
+
+def col_reorder_device(rows, cols, row_offsets, col_indices, reordered_rows, delta, device=0):
+    """bsmr_col_reorder: (status, dict of the ten arrays named as in ARRAY_IDS, device ms)"""
+    ro = np.ascontiguousarray(row_offsets, dtype=np.uint32)
+    ci = np.ascontiguousarray(col_indices, dtype=np.uint32)
+    rr = np.ascontiguousarray(reordered_rows, dtype=np.uint32)
+    h = C.c_void_p()
+    st = hip().bsmr_col_reorder(C.byref(h), device, rows, cols, _ptr(ro), _ptr(ci), _ptr(rr), rr.size, delta)
+    if st != OK:
+        return st, None, 0.0
+    sz = ColReorderSizes()
+    hip().bsmr_col_reorder_sizes(h, C.byref(sz))
+    P1 = sz.num_row_panels + 1
+    out = {"denseCols": np.zeros(sz.num_dense_cols, np.uint32), "denseColOffsets": np.zeros(P1, np.uint32),
+           "sparseCols": np.zeros(sz.num_sparse_cols, np.uint32), "sparseColOffsets": np.zeros(P1, np.uint32),
+           "sparseValueOffsets": np.zeros(P1, np.uint32), "blockOffsets": np.zeros(P1, np.uint32),
+           "blockValues": np.zeros(sz.num_blocks * 256, np.uint32), "sparseValues": np.zeros(sz.num_sparse_entries, np.uint32),
+           "sparseRelativeRows": np.zeros(sz.num_sparse_entries, np.uint32),
+           "sparseColIndices": np.zeros(sz.num_sparse_entries, np.uint32)}
+    order = ("denseCols", "denseColOffsets", "sparseCols", "sparseColOffsets", "sparseValueOffsets", "blockOffsets",
+             "blockValues", "sparseValues", "sparseRelativeRows", "sparseColIndices")
+    st = hip().bsmr_col_reorder_fetch(h, *[_ptr(out[k]) for k in order])
+    hip().bsmr_col_reorder_free(h)
+    return st, out, sz.elapsed_ms
 
 
 def partition_rows_by_cost(csr: CSR, world: int) -> list:

@@ -86,7 +86,9 @@ void BSMR::rowReordering(const float similarityThreshold, const sparseMatrix::CS
             const bool present = choice != "host" && bsmr_device_count(&count) == BSMR_OK && count > 0;
             UIN nonEmpty = 0;
             for (UIN r = 0; r < matrix.row(); ++r) nonEmpty += matrix.rowOffsets()[r + 1] > matrix.rowOffsets()[r];
-            const bool longRows = nonEmpty && matrix.nnz() / nonEmpty >= 32;
+            // long rows (dense device scan wins) and enough of them to repay ~8 us per speculative pass: nips-like
+            // (1 500 rows of ~500 entries) clusters in 96 ms on the host against 138-185 ms on the device
+            const bool longRows = nonEmpty >= 4096 && matrix.nnz() / nonEmpty >= 32;
             device = present && (choice == "device" || longRows) ? std::min(pipelineDevice(), count - 1) : -1;
         }
         if (device < 0 ||
@@ -106,11 +108,25 @@ void BSMR::colReordering(const float blockDensityThreshold, const sparseMatrix::
     }
     const int iters = std::max(1, numIterations);
     float total = 0.0f;
+    int device = colReorderingDevice();
+    if (device == -2) {   // automatic: large matrices on the pipeline's device
+        const char* env = std::getenv("BSMR_COLREORDER");
+        const std::string choice = env ? env : "";
+        int count = 0;
+        const bool present = choice != "host" && bsmr_device_count(&count) == BSMR_OK && count > 0;
+        device = present && (choice == "device" || matrix.nnz() >= (4u << 20)) ? std::min(pipelineDevice(), count - 1) : -1;
+    }
     for (int i = 0; i < iters; ++i) {
         float once = 0.0f;
-        colReordering_cpu(matrix, static_cast<UIN>(numRowPanels_), reorderedRows_, blockDensityThreshold,
-                          denseCols_, denseColOffsets_, sparseCols_, sparseColOffsets_,
-                          sparseValueOffsets_, once);
+        deviceRphm_ = DeviceRphmArrays{};
+        if (device < 0 || !colReordering_device(matrix, reorderedRows_, blockDensityThreshold, device, denseCols_,
+                                                denseColOffsets_, sparseCols_, sparseColOffsets_, sparseValueOffsets_,
+                                                deviceRphm_, once)) {
+            deviceRphm_ = DeviceRphmArrays{};
+            colReordering_cpu(matrix, static_cast<UIN>(numRowPanels_), reorderedRows_, blockDensityThreshold,
+                              denseCols_, denseColOffsets_, sparseCols_, sparseColOffsets_,
+                              sparseValueOffsets_, once);
+        }
         total += once;
     }
     colReorderingTime_ = total / iters;
@@ -154,8 +170,17 @@ RPHM::RPHM(const sparseMatrix::CSR<float>& matrix, const BSMR& bsmr, int device)
     }
 
     const size_t numBlocks = blockOffsets_.back();
-    blockValues_.assign(numBlocks * BLOCK_SIZE, NULL_VALUE);
     const size_t numSparse = sparseValueOffsets_.empty() ? 0 : sparseValueOffsets_.back();
+    const BSMR::DeviceRphmArrays& fromDevice = bsmr.deviceRphm();
+    const bool useDeviceArrays = fromDevice.valid && fromDevice.blockOffsets == blockOffsets_ &&
+                                 fromDevice.blockValues.size() == numBlocks * BLOCK_SIZE && fromDevice.sparseValues.size() == numSparse;
+    if (useDeviceArrays) {   // the column reordering ran on the device and produced the index arrays in the same pass
+        blockValues_ = fromDevice.blockValues;
+        sparseValues_ = fromDevice.sparseValues;
+        sparseRelativeRows_ = fromDevice.sparseRelativeRows;
+        sparseColIndices_ = fromDevice.sparseColIndices;
+    } else {
+    blockValues_.assign(numBlocks * BLOCK_SIZE, NULL_VALUE);
     sparseValues_.resize(numSparse);
     sparseRelativeRows_.resize(numSparse);
     sparseColIndices_.resize(numSparse);
@@ -187,6 +212,7 @@ RPHM::RPHM(const sparseMatrix::CSR<float>& matrix, const BSMR& bsmr, int device)
                 }
             }
         }
+    }
     }
     reorderingTime_ = std::chrono::duration<float, std::milli>(Clock::now() - t0).count();
 

@@ -20,6 +20,7 @@
 #include "util.hpp"
 
 #include "BSMR.hpp"
+#include "bsmr_hip.h"
 
 std::pair<UIN, UIN> analysisDescendingOrderColSegment(
     const float blockDensityThreshold, const std::vector<UIN>& numOfNonZeroInEachColSegment) {
@@ -115,4 +116,47 @@ void colReordering_cpu(const sparseMatrix::CSR<float>& matrix, const UIN numRowP
     }
 
     time = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// ---------------------------------------------------------------------------
+// device path: bsmr_col_reorder, csrc/colreorder_capi.hpp
+// ---------------------------------------------------------------------------
+namespace {
+int g_colReorderingDevice = -2;
+}
+void setColReorderingDevice(int device) { g_colReorderingDevice = device; }
+int colReorderingDevice() { return g_colReorderingDevice; }
+
+bool colReordering_device(const sparseMatrix::CSR<float>& matrix, const std::vector<UIN>& reorderedRows,
+                          const float blockDensityThreshold, int device, std::vector<UIN>& denseCols,
+                          std::vector<UIN>& denseColOffsets, std::vector<UIN>& sparseCols,
+                          std::vector<UIN>& sparseColOffsets, std::vector<UIN>& sparseDataOffsets,
+                          BSMR::DeviceRphmArrays& rphm, float& time) {
+    const auto t0 = std::chrono::steady_clock::now();
+    bsmr_colreorder* h = nullptr;
+    const int st = bsmr_col_reorder(&h, device, matrix.row(), matrix.col(), matrix.rowOffsets().data(),
+                                    matrix.colIndices().data(), reorderedRows.data(),
+                                    static_cast<uint32_t>(reorderedRows.size()), blockDensityThreshold);
+    if (st != BSMR_OK) return false;
+    bsmr_colreorder_sizes sz{};
+    bsmr_col_reorder_sizes(h, &sz);
+    denseCols.resize(sz.num_dense_cols);
+    sparseCols.resize(sz.num_sparse_cols);
+    denseColOffsets.resize(static_cast<size_t>(sz.num_row_panels) + 1);
+    sparseColOffsets.resize(static_cast<size_t>(sz.num_row_panels) + 1);
+    sparseDataOffsets.resize(static_cast<size_t>(sz.num_row_panels) + 1);
+    rphm.blockOffsets.resize(static_cast<size_t>(sz.num_row_panels) + 1);
+    rphm.blockValues.resize(sz.num_blocks * BLOCK_SIZE);
+    rphm.sparseValues.resize(sz.num_sparse_entries);
+    rphm.sparseRelativeRows.resize(sz.num_sparse_entries);
+    rphm.sparseColIndices.resize(sz.num_sparse_entries);
+    const int fs = bsmr_col_reorder_fetch(h, denseCols.data(), denseColOffsets.data(), sparseCols.data(), sparseColOffsets.data(),
+                                          sparseDataOffsets.data(), rphm.blockOffsets.data(), rphm.blockValues.data(),
+                                          rphm.sparseValues.data(), rphm.sparseRelativeRows.data(), rphm.sparseColIndices.data());
+    bsmr_col_reorder_free(h);
+    if (fs != BSMR_OK) return false;
+    rphm.valid = true;
+    rphm.deviceMs = sz.elapsed_ms;
+    time = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return true;
 }

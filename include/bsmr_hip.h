@@ -23,6 +23,8 @@
  *                           src/sddmmKernel.cu:2764-2869, 2486-2515)
  *   bsmr_cluster_rows    <- bsa_rowReordering_gpu (src/rowReordering.cu:1027-1095): the row
  *                           clustering on the device, same row order and cluster count
+ *   bsmr_col_reorder*    <- colReordering_cpu + the index arrays of RPHM::RPHM (src/colReordering.cu:274-404,
+ *                           src/BSMR.cpp:83-265) on the device; the reference's colReordering_gpu (:146-241) is unfinished
  *   bsmr_convert_operands / bsmr_sddmm_lowp
  *                        <- no reference counterpart (the reference converts to
  *                           TF32 in registers); lets a caller that already holds
@@ -208,6 +210,30 @@ int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const uint32_t *
                       const uint32_t *col_indices, uint32_t bin_width, float alpha,
                       uint32_t *reordered_rows, uint32_t *num_reordered, int32_t *num_clusters,
                       bsmr_cluster_stats *stats);
+
+/* Column reordering, dense / sparse split and the RPHM index arrays of the BSMR pipeline on the device:
+ * colReordering_cpu (src/colReordering.cu:274-404; the reference's own GPU version, :146-241, is unfinished) followed by
+ * the array part of RPHM::RPHM (src/BSMR.cpp:83-265).  S as host CSR, reordered_rows as BSMR::rowReordering returns
+ * them (the non-empty rows in clustered order).  The results equal the host implementation's array for array:
+ * bsmr_col_reorder computes them on `device`, bsmr_col_reorder_sizes tells how much room they need, and
+ * bsmr_col_reorder_fetch copies them into the caller's arrays (any pointer may be NULL). */
+typedef struct bsmr_colreorder bsmr_colreorder;
+typedef struct bsmr_colreorder_sizes {
+    uint32_t num_row_panels;
+    uint64_t num_dense_cols;      /* length of denseCols  (multiples of 16 per panel)          */
+    uint64_t num_sparse_cols;     /* length of sparseCols (padding sentinels included)          */
+    uint64_t num_blocks;          /* dense 16 x 16 blocks: blockValues holds 256 words of each  */
+    uint64_t num_sparse_entries;  /* length of sparseValues / sparseRelativeRows / sparseColIndices */
+    float    elapsed_ms;          /* device time, uploads included                              */
+} bsmr_colreorder_sizes;
+int bsmr_col_reorder(bsmr_colreorder **out, int device, uint32_t rows, uint32_t cols, const uint32_t *row_offsets,
+                     const uint32_t *col_indices, const uint32_t *reordered_rows, uint32_t num_reordered, float delta);
+int bsmr_col_reorder_sizes(const bsmr_colreorder *h, bsmr_colreorder_sizes *out);
+int bsmr_col_reorder_fetch(const bsmr_colreorder *h, uint32_t *dense_cols, uint32_t *dense_col_offsets,
+                           uint32_t *sparse_cols, uint32_t *sparse_col_offsets, uint32_t *sparse_value_offsets,
+                           uint32_t *block_offsets, uint32_t *block_values, uint32_t *sparse_values,
+                           uint32_t *sparse_relative_rows, uint32_t *sparse_col_indices);
+int bsmr_col_reorder_free(bsmr_colreorder *h);
 
 /* How the sparse residue of a call (K, compute_mode) will run: lanes that share one entry's
  * K-long dot product (the fp32 summation order of the residue depends on it; the CPU twin in

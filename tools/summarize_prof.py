@@ -31,14 +31,14 @@ out = {"bench": {k: bench[k] for k in ("value", "ms_per_step", "kernels_ms", "ro
 # HBM traffic of the dominant kernel, per launch: FETCH_SIZE / WRITE_SIZE are in KiB; gfx950
 # FETCH_SIZE counts half of a 16-B-per-lane stream (MI355X_MICROARCH.md "HBM"), so it is doubled.
 dom = bench["roofline"]["kernel"]
-names = {"dense": ("denseStream", "denseGroups"), "sparse": ("sparseEntries",), "convert": ("convertOperands",)}[dom]
+names = {"dense": ("denseStream", "denseGroups", "denseTiles", "denseShared"), "sparse": ("sparseEntries",), "convert": ("convertOperands",)}[dom]
 for k, c in pmc.items():
     if any(n in k for n in names) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         traffic = int((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
         out["traffic_bytes_per_launch"] = traffic
         tfile = dst / "traffic.json"
         t = json.loads(tfile.read_text()) if tfile.exists() else {}
-        t[f"{workload}:{mode}:{dom}"] = traffic
+        t[f"{workload}:{mode}:{dom}"] = {"bytes": traffic, "source": f"profiles/{rnd}_{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of the same bench command; 2 x FETCH_SIZE + WRITE_SIZE)"}
         tfile.write_text(json.dumps(t, indent=1))
 (dst / f"{rnd}_{tag}_pmc.json").write_text(json.dumps(out, indent=1))
 print(open(dst / f"{rnd}_{tag}_kernel_stats.csv").read()[:1500])
