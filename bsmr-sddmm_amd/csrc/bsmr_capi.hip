@@ -43,6 +43,7 @@ struct DenseFormat {
     uint32_t* winMask = nullptr;   // STAGED only
     uint32_t* blockCols = nullptr;
     uint8_t* tiles8 = nullptr;     // STAGED destination tiles
+    bsmr::TileMask* tilesM = nullptr;   // ... in the mask form (then tiles8 is absent)
     uint16_t* tiles16 = nullptr;   // DIRECT
     uint32_t* tiles32 = nullptr;
     uint8_t* blockMask = nullptr;
@@ -176,7 +177,7 @@ int envInt(const char* name, int fallback) {
 
 void freePlanDevice(bsmr_plan* p) {
     for (DenseFormat& f : p->fmt) {
-        void* ptrs[] = {f.groupRows, f.rowBase, f.winLen, f.winMask, f.blockCols, f.tiles8,
+        void* ptrs[] = {f.groupRows, f.rowBase, f.winLen, f.winMask, f.blockCols, f.tiles8, f.tilesM,
                         f.tiles16,   f.tiles32, f.blockMask, f.items};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
@@ -230,6 +231,11 @@ int uploadDense(DenseFormat& f, const bsmr::PackedPlan& pk, uint64_t& bytes) {
     if (st == BSMR_OK) st = upload(f.winMask, pk.winMask, bytes);
     if (st == BSMR_OK) st = upload(f.blockCols, pk.blockCols, bytes);
     if (st == BSMR_OK) st = upload(f.tiles8, pk.tiles8, bytes);
+    if (st == BSMR_OK) {
+        uint32_t* words = nullptr;
+        st = upload(words, pk.tilesMask, bytes);
+        f.tilesM = reinterpret_cast<bsmr::TileMask*>(words);
+    }
     if (st == BSMR_OK) st = upload(f.tiles16, pk.tiles16, bytes);
     if (st == BSMR_OK) st = upload(f.tiles32, pk.tiles32, bytes);
     if (st == BSMR_OK) st = upload(f.blockMask, pk.blockMask, bytes);
@@ -303,6 +309,7 @@ int launchStreamT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
 
 template <int KS, int MODE>
 int launchStream(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+    if (f.tilesM) return launchStreamT<KS, MODE, bsmr::TileMask>(f, A16, B16, f.tilesM, P, s);
     if (f.tiles8) return launchStreamT<KS, MODE, uint8_t>(f, A16, B16, f.tiles8, P, s);
     return f.tiles16 ? launchStreamT<KS, MODE, uint16_t>(f, A16, B16, f.tiles16, P, s)
                      : launchStreamT<KS, MODE, uint32_t>(f, A16, B16, f.tiles32, P, s);
@@ -310,6 +317,7 @@ int launchStream(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16,
 
 template <int KS, int H, int NB, int MODE>
 int launchGroups(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+    if (f.tilesM) return launchGroupsT<KS, H, NB, MODE, bsmr::TileMask, false>(f, A16, B16, f.tilesM, P, s);
     if (f.tiles8)
         return f.stageInLds ? launchGroupsT<KS, H, NB, MODE, uint8_t, true>(f, A16, B16, f.tiles8, P, s)
                             : launchGroupsT<KS, H, NB, MODE, uint8_t, false>(f, A16, B16, f.tiles8, P, s);
@@ -569,7 +577,11 @@ int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uin
     default: break;
     }
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
-    if (f.tiles8)
+    if (f.tilesM)
+        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, bsmr::TileMask>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A16,
+                           B16, K, f.H, f.groupRows, f.rowBase, f.blockCols, f.tilesM, f.blockMask, f.items,
+                           f.numItems, P, g_batch);
+    else if (f.tiles8)
         hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint8_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A16,
                            B16, K, f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items,
                            f.numItems, P, g_batch);
@@ -591,7 +603,10 @@ int launchDenseCvt(const bsmr_plan* p, uint32_t K, const float* A, const float* 
     const DenseFormat& f = p->fmt[0];
     if (f.numItems == 0) return BSMR_OK;
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
-    if (f.tiles8)
+    if (f.tilesM)
+        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, bsmr::TileMask>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tilesM, f.blockMask, f.items, f.numItems, P, g_batch);
+    else if (f.tiles8)
         hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint8_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
                            f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items, f.numItems, P, g_batch);
     else if (f.tiles16)
@@ -609,7 +624,10 @@ int launchDense32(const bsmr_plan* p, uint32_t K, const float* A, const float* B
     const DenseFormat& f = p->fmt[0];
     if (f.numItems == 0) return BSMR_OK;
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
-    if (f.tiles8)
+    if (f.tilesM)
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<bsmr::TileMask>, dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
+                           f.groupRows, f.rowBase, f.blockCols, f.tilesM, f.blockMask, f.items, f.numItems, P, g_batch);
+    else if (f.tiles8)
         hipLaunchKernelGGL(bsmr::denseGroupsF32<uint8_t>, dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
                            f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items, f.numItems, P, g_batch);
     else if (f.tiles16)
@@ -944,6 +962,7 @@ int bsmr_plan_options_default(bsmr_plan_options* opt) {
     o.b_only = 1;
     o.b_only_work_m = 100;
     o.overlap_streams = -1;
+    o.mask_tiles = -1;
     *opt = o;
     return BSMR_OK;
 }
@@ -969,6 +988,7 @@ int bsmr_plan_options_from_env(bsmr_plan_options* opt) {
         {"BSMR_SPARSE_LPE", &o.sparse_lpe}, {"BSMR_FREE_RESIDUE", &o.free_residue},
         {"BSMR_CONVERT_IN_KERNEL", &o.convert_in_kernel}, {"BSMR_CONVERT_SLICED", &o.convert_sliced}, {"BSMR_B_ONLY", &o.b_only},
         {"BSMR_B_ONLY_WORK_M", &o.b_only_work_m}, {"BSMR_OVERLAP_STREAMS", &o.overlap_streams},
+        {"BSMR_MASK_TILES", &o.mask_tiles},
     };
     for (const auto& k : knobs) *k.field = envInt(k.name, *k.field);
     return BSMR_OK;
@@ -1103,6 +1123,11 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         // scattered; 2 = 8-bit window offsets, assembled in LDS and stored coalesced
         const int outputMode = o.output_mode;
         opt.staged = outputMode != 0;
+        // mask form of the tiles (48 instead of 256 bytes each): the streaming kernel carries 3 instead of 1 register per
+        // tile and pays a popcount per element, which costs 3-9 % while the 8-bit tiles fit the L2s (nips-like K=128
+        // 9.3 -> 10.1 us, mycielskian15 34.9 -> 36.2) and wins once they do not (reddit-like shard, 119 MB of tiles:
+        // 317 -> 295 us).  -1 = by that size; (mode 2 assembles the 8-bit windows in LDS)
+        opt.maskTiles = outputMode == 1 && (o.mask_tiles > 0 || (o.mask_tiles < 0 && (uint64_t)d->block_offsets[P] * 256ull > (32ull << 20)));
         bsmr::PackedPlan pk;
         st = bsmr::packPlan(d, opt, pk);
         if (st != BSMR_OK) return st;

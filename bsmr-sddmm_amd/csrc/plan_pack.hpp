@@ -88,6 +88,7 @@ struct PackOptions {
     bool forceWideTiles = false;
     bool columnOrder = true;  // blocks in column-id order, items sorted by first column
     bool staged = true;       // try the staged (LDS window) destination encoding
+    bool maskTiles = true;    // ... and from it the mask form (48 bytes per tile) when every tile row's entries are consecutive
     int freeResidue = 0;      // 1: residue in global column order instead of per panel (cross-check only)
 };
 
@@ -102,6 +103,7 @@ struct PackedPlan {
     std::vector<uint32_t> winMask;        // STAGED: [items*16H*8] ownership bitmap of the window
     std::vector<uint32_t> blockCols;      // [NB*16]
     std::vector<uint8_t> tiles8;          // STAGED: [NB*H*256]
+    std::vector<uint32_t> tilesMask;      // mask form of the STAGED tiles: [NB*H*12] (then tiles8 is empty)
     std::vector<uint16_t> tiles16;        // DIRECT
     std::vector<uint32_t> tiles32;        // DIRECT, rows with >= 65535 entries
     std::vector<uint8_t> blockMask;       // [NB]
@@ -430,6 +432,38 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
                         }
             }
         });
+        // Mask form: a tile row's window offsets are consecutive (blocks in column order, sorted CSR rows, no entry of
+        // another path in between) in every tile -> 16-bit column mask + first offset per row, 48 bytes per tile.
+        if (opt.maskTiles) {
+            const size_t numTiles = out.numBlocks * H;
+            std::vector<uint32_t> words(numTiles * 12, 0);
+            std::vector<uint8_t> bad(packThreads(), 0);
+            parallelChunks(numTiles, 256, [&](size_t t0, size_t t1, size_t w) {
+                for (size_t t = t0; t < t1 && !bad[w]; ++t) {
+                    const uint8_t* tile = &out.tiles8[t * 256];
+                    for (uint32_t row = 0; row < 16; ++row) {
+                        uint32_t mask = 0, first = 0, expect = 0;
+                        for (uint32_t c = 0; c < 16; ++c) {
+                            const uint32_t off = tile[((row >> 2) * 16 + c) * 4 + (row & 3)];   // lane-major: lane = (row / 4) * 16 + c
+                            if (off == 0xFF) continue;
+                            if (!mask) first = off;
+                            else if (off != expect) { bad[w] = 1; break; }
+                            expect = off + 1;
+                            mask |= 1u << c;
+                        }
+                        uint32_t* group = &words[t * 12 + (row >> 2) * 3];
+                        group[(row & 3) >> 1] |= mask << (16 * (row & 1));
+                        group[2] |= first << (8 * (row & 3));
+                    }
+                }
+            });
+            bool ok = true;
+            for (const uint8_t b : bad) ok = ok && !b;
+            if (ok) {
+                out.tilesMask.swap(words);
+                std::vector<uint8_t>().swap(out.tiles8);
+            }
+        }
     } else {
         out.denseItems.clear();
         for (uint32_t gi = 0; gi < G; ++gi)

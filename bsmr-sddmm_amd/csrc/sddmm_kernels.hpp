@@ -44,6 +44,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
 constexpr int kWave = 64;
 constexpr int kThreads = 256;           // 4 waves per workgroup
@@ -137,6 +138,7 @@ convertOperands(const float* __restrict__ A, uint64_t nA8, const float* __restri
 template <typename TileT> struct TileLoad;
 template <> struct TileLoad<uint16_t> {
     typedef uint32_t raw __attribute__((ext_vector_type(2)));
+    static constexpr bool windowed = false;
     static constexpr uint32_t kNull = 0xFFFFu;
     static __device__ __forceinline__ uint32_t get(const raw& v, int i) {
         const uint32_t w = i < 2 ? v[0] : v[1];
@@ -145,11 +147,25 @@ template <> struct TileLoad<uint16_t> {
 };
 template <> struct TileLoad<uint8_t> {   // staged form: offsets into the item's per-row window
     typedef uint32_t raw;
+    static constexpr bool windowed = true;
     static constexpr uint32_t kNull = 0xFFu;
     static __device__ __forceinline__ uint32_t get(const raw& v, int i) { return (v >> (8 * i)) & 0xFFu; }
 };
+// Mask form (the default whenever it applies): the sparse mask itself.  With the blocks in column-id order and sorted CSR
+// rows the entries a tile holds of one row are consecutive positions of that row's window, so a tile is 16 x (16-bit
+// column mask, 8-bit window offset of the row's first entry): 48 bytes instead of the 256 of the 8-bit form (the
+// reference's tile: 1 KiB, src/BSMR.cpp:143-174).  Per 4 rows of a lane group: {mask01, mask23, four offsets}; lane
+// (g, c) finds its destination as offset + popcount(mask below bit c).
+struct TileMask {
+    uint32_t word;
+};
+template <> struct TileLoad<TileMask> {
+    typedef u32x3 raw;
+    static constexpr bool windowed = true;
+};
 template <> struct TileLoad<uint32_t> {
     typedef u32x4 raw;
+    static constexpr bool windowed = false;
     static constexpr uint32_t kNull = 0xFFFFFFFFu;
     static __device__ __forceinline__ uint32_t get(const raw& v, int i) { return v[i]; }
 };
@@ -157,16 +173,31 @@ template <> struct TileLoad<uint32_t> {
 template <typename TileT>
 __device__ __forceinline__ typename TileLoad<TileT>::raw loadTile(const TileT* __restrict__ tiles,
                                                                   size_t tileId, uint32_t lane) {
-    return *reinterpret_cast<const typename TileLoad<TileT>::raw*>(tiles + tileId * 256u + lane * 4u);
+    if constexpr (sizeof(TileT) == sizeof(TileMask) && TileLoad<TileT>::windowed) {   // mask form: 12 words per tile
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(tiles) + tileId * 12u + (lane >> 4) * 3u;
+        return u32x3{words[0], words[1], words[2]};
+    } else {
+        return *reinterpret_cast<const typename TileLoad<TileT>::raw*>(tiles + tileId * 256u + lane * 4u);
+    }
 }
 
 template <typename TileT>
 __device__ __forceinline__ void scatterTile(const f32x4& acc, const typename TileLoad<TileT>::raw& tile,
                                             const uint32_t* rowBase, float* __restrict__ P) {
+    if constexpr (sizeof(TileT) == sizeof(TileMask) && TileLoad<TileT>::windowed) {
+        const uint32_t c = threadIdx.x & 15u, below = (1u << c) - 1u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t off = TileLoad<TileT>::get(tile, i);
-        if (off != TileLoad<TileT>::kNull) P[rowBase[i] + off] = acc[i];
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t m = ((i < 2 ? tile[0] : tile[1]) >> (16 * (i & 1))) & 0xFFFFu;
+            const uint32_t first = (tile[2] >> (8 * i)) & 0xFFu;
+            if ((m >> c) & 1u) P[rowBase[i] + first + __builtin_popcount(m & below)] = acc[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t off = TileLoad<TileT>::get(tile, i);
+            if (off != TileLoad<TileT>::kNull) P[rowBase[i] + off] = acc[i];
+        }
     }
 }
 
@@ -213,8 +244,9 @@ denseGroups(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     //   winMask); without it the results are scattered straight into the windows.
     // 16/32-bit tiles: offsets from the row's first dense entry; rowBaseTable is indexed
     //   by group; results are scattered straight to P.
-    constexpr bool WINDOWED = sizeof(TileT) == 1;
+    constexpr bool WINDOWED = TileLoad<TileT>::windowed;
     constexpr bool STAGED = WINDOWED && LDS_STAGE;
+    static_assert(!LDS_STAGE || sizeof(TileT) == 1, "windows are staged in LDS from the 8-bit form only");
     constexpr uint32_t K = 32u * KS;
     constexpr uint32_t PC = 4u * KS;                 // 16-byte pieces per column
     constexpr uint32_t SW = PC - 1u < 15u ? PC - 1u : 15u;
@@ -435,7 +467,7 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     constexpr uint32_t SW = PC - 1u < 15u ? PC - 1u : 15u;
     constexpr uint32_t rowBytes = 64u * KSL;          // one column of an image
     constexpr uint32_t blkBytes = 16u * rowBytes;     // one image
-    constexpr bool WINDOWED = sizeof(TileT) == 1;
+    constexpr bool WINDOWED = TileLoad<TileT>::windowed;
     constexpr uint32_t CREG = (MAXB + 3) / 4;
     constexpr uint32_t SLOTS = streamSlots(KS);
     typedef typename TileLoad<TileT>::raw TileRaw;
@@ -598,7 +630,7 @@ denseGroupsAnyK(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B
             uint32_t rowBase[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                rowBase[i] = groupRowBase[(sizeof(TileT) == 1 ? itemId * 16u * H + h * 16u : slot) + 4u * g + i];
+                rowBase[i] = groupRowBase[(TileLoad<TileT>::windowed ? itemId * 16u * H + h * 16u : slot) + 4u * g + i];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (uint32_t s = 0; s < steps; ++s) {
                 const u32x4 av = *reinterpret_cast<const u32x4*>(aRow + s * 32u);
@@ -643,7 +675,7 @@ denseGroupsCvt(const float* __restrict__ A, const float* __restrict__ B, uint32_
             uint32_t rowBase[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                rowBase[i] = groupRowBase[(sizeof(TileT) == 1 ? itemId * 16u * H + h * 16u : slot) + 4u * g + i];
+                rowBase[i] = groupRowBase[(TileLoad<TileT>::windowed ? itemId * 16u * H + h * 16u : slot) + 4u * g + i];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (uint32_t s = 0; s < steps; ++s) {
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(aRow + s * 32u);
@@ -690,7 +722,7 @@ denseGroupsF32(const float* __restrict__ A, const float* __restrict__ B, uint32_
             uint32_t rowBase[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                rowBase[i] = groupRowBase[(sizeof(TileT) == 1 ? itemId * 16u * H + h * 16u : slot) + 4u * g + i];
+                rowBase[i] = groupRowBase[(TileLoad<TileT>::windowed ? itemId * 16u * H + h * 16u : slot) + 4u * g + i];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (uint32_t t = 0; t < steps; ++t) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(aRow + t * 16u);

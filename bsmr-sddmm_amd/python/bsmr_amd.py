@@ -62,7 +62,7 @@ class PlanOptions(C.Structure):
         "promote_head", "dense_group", "dense_blocks_per_item", "stream_waves", "output_mode", "force_tile32",
         "column_order", "dense_stream", "dense_batch", "tile_group", "tile_blocks_per_item", "tile_depth",
         "sparse_entries_per_item", "sparse_lowp", "sparse_lpe", "free_residue", "convert_in_kernel", "convert_sliced",
-        "b_only", "b_only_work_m", "overlap_streams")]
+        "b_only", "b_only_work_m", "overlap_streams", "mask_tiles")]
 
 
 ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED = 0, 1, 2

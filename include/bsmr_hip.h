@@ -174,6 +174,9 @@ typedef struct bsmr_plan_options {
     /* launch */
     int32_t  overlap_streams;       /* dense and residue kernels of a hybrid plan on two streams joined by events:
                                        -1 = when both parts are large enough, 0 = never, 1 = always      [OVERLAP_STREAMS] */
+    int32_t  mask_tiles;            /* destination tiles as 16-bit column masks + first offsets (48 instead of 256 bytes
+                                       per tile; needs consecutive entries per tile row): 1 = whenever possible, 0 = never,
+                                       -1 = when the 8-bit tiles would exceed the 32 MiB of L2 (default)     [MASK_TILES] */
 } bsmr_plan_options;
 int bsmr_plan_options_default(bsmr_plan_options *opt);
 /* defaults, then every BSMR_<NAME> variable that is set */

@@ -100,7 +100,7 @@ extern "C" int plancheck_promote(const bsmr_rphm_desc* in, uint32_t minAverage, 
     out[9] = (uint64_t)(nowUs() - t0);
     out[10] = bsmr::countUnionColumns(d, 1);
     out[11] = bsmr::countUnionColumns(d, 4);
-    out[12] = !pk.tiles8.empty() ? 1 : !pk.tiles16.empty() ? 2 : !pk.tiles32.empty() ? 4 : 0;
+    out[12] = !pk.tiles8.empty() || !pk.tilesMask.empty() ? 1 : !pk.tiles16.empty() ? 2 : !pk.tiles32.empty() ? 4 : 0;
     out[6] = pk.numDenseEntries;
     out[7] = pk.numSparseEntries;
     return 0;

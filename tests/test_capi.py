@@ -74,7 +74,7 @@ def test_plan_options_defaults_and_environment_override(engine, monkeypatch):
     o = engine.plan_options()
     assert o.struct_size == C.sizeof(engine.PlanOptions)
     assert (o.dense_engine, o.fold_dense_below, o.promote_average, o.promote_column_degree) == (0, 32768, 16, 32)
-    assert (o.output_mode, o.column_order, o.sparse_lowp, o.convert_in_kernel, o.b_only, o.overlap_streams) == (1, 1, 1, -1, 1, -1)
+    assert (o.output_mode, o.column_order, o.sparse_lowp, o.convert_in_kernel, o.b_only, o.overlap_streams, o.mask_tiles) == (1, 1, 1, -1, 1, -1, -1)
     for name in ("BSMR_FOLD_DENSE_BELOW", "BSMR_DENSE_ENGINE", "BSMR_TILE_GROUP", "BSMR_OVERLAP_STREAMS"):
         monkeypatch.delenv(name, raising=False)
     e = engine.PlanOptions()

@@ -153,6 +153,8 @@ def test_large_k_sparse_without_lds(engine, oracle):
     {"BSMR_DENSE_BLOCKS_PER_WG": "8"}, {"BSMR_DENSE_BLOCKS_PER_WG": "32"},
     {"BSMR_DENSE_GROUP": "2", "BSMR_DENSE_BLOCKS_PER_WG": "8"}, {"BSMR_DENSE_GROUP": "2", "BSMR_DENSE_BLOCKS_PER_WG": "3"},
     {"BSMR_FREE_RESIDUE": "1"}, {"BSMR_FREE_RESIDUE": "1", "BSMR_SPARSE_LOWP": "0"}, {"BSMR_FREE_RESIDUE": "0"},
+    {"BSMR_MASK_TILES": "1"}, {"BSMR_MASK_TILES": "1", "BSMR_DENSE_GROUP": "4"}, {"BSMR_MASK_TILES": "1", "BSMR_DENSE_GROUP": "2", "BSMR_DENSE_BLOCKS_PER_WG": "3"},
+    {"BSMR_MASK_TILES": "1", "BSMR_CONVERT_IN_KERNEL": "1"}, {"BSMR_MASK_TILES": "0"},
 ])
 @pytest.mark.parametrize("K", [32, 128, 512])
 def test_plan_knobs(engine, oracle, monkeypatch, knobs, K):
@@ -234,8 +236,11 @@ def test_unsorted_csr_rows_fall_back_to_direct_scatter(engine, oracle):
         check_case(engine, oracle, rows, cols, ro, ci_sorted, K, 0.3, 0.0, 0)
 
 
-def test_output_indexing_is_exact(engine, oracle):
-    """A = one-hot rows, B = column id: every entry's exact value identifies (row, col)."""
+@pytest.mark.parametrize("mask_tiles", ["0", "1"])
+def test_output_indexing_is_exact(engine, oracle, monkeypatch, mask_tiles):
+    """A = one-hot rows, B = column id: every entry's exact value identifies (row, col).  Both destination encodings of
+    the window form: 8-bit offsets and the mask form (column mask + first offset per tile row, bsmr_plan_options.mask_tiles)."""
+    monkeypatch.setenv("BSMR_MASK_TILES", mask_tiles)
     rows, cols, ro, ci = synth.random_pattern(130, 500, 4000, seed=21, empty_rows=4)
     K = 32
     A = np.zeros((rows, K), dtype=np.float32)
