@@ -508,8 +508,47 @@ int launchSharedT(const TileFormatDev& t, int device, uint32_t numCols, const ui
         auto kernel = bsmr::denseShared<KS, HW, MODE>;
         const size_t lds = bsmr::sharedLdsBytes(KS, HW);
         if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, device)) return st;
+#ifdef BSMR_LAB_STAMPS
+        if (envInt("BSMR_TILE_STAMPS", 0)) {   // lab: one stamped launch, phase statistics on stderr (one record per wave)
+            uint64_t* dev = nullptr;
+            const size_t nrec = (size_t)t.numItems * 4, n = nrec * 8;
+            BSMR_HIP(hipMalloc(reinterpret_cast<void**>(&dev), n * 8));
+            BSMR_HIP(hipMemset(dev, 0, n * 8));
+            hipLaunchKernelGGL(kernel, dim3(t.numItems, 1), dim3(bsmr::kThreads), lds, s, A16, B16, t.groupRows, t.blockCols,
+                               reinterpret_cast<const uint4*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P, numCols, g_batch, dev);
+            BSMR_HIP(hipStreamSynchronize(s));
+            std::vector<uint64_t> h(n);
+            BSMR_HIP(hipMemcpy(h.data(), dev, n * 8, hipMemcpyDeviceToHost));
+            (void)hipFree(dev);
+            uint64_t first = ~0ull;
+            for (size_t i = 0; i < nrec; ++i) first = std::min(first, h[i * 8]);
+            auto med = [&](auto f) {
+                std::vector<double> v(nrec);
+                for (size_t i = 0; i < nrec; ++i) v[i] = f(&h[i * 8]);
+                std::sort(v.begin(), v.end());
+                return std::make_pair(v[v.size() / 2], v[v.size() * 9 / 10]);
+            };
+            auto pr = [&](const char* name, std::pair<double, double> m) { fprintf(stderr, "  %-26s median %9.0f  p90 %9.0f\n", name, m.first, m.second); };
+            fprintf(stderr, "[shared stamps] KS=%d HW=%d items=%u blocks=%llu lds=%zu\n", KS, HW, t.numItems, (unsigned long long)t.numBlocks, lds);
+            pr("start offset", med([&](const uint64_t* q) { return (double)(q[0] - first); }));
+            pr("prologue (ids, rows)", med([&](const uint64_t* q) { return (double)(q[1] - q[0]); }));
+            pr("A fragments + step 0", med([&](const uint64_t* q) { return (double)(q[2] - q[1]); }));
+            pr("loop", med([&](const uint64_t* q) { return (double)(q[3] - q[2]); }));
+            pr("store drain", med([&](const uint64_t* q) { return (double)(q[4] - q[3]); }));
+            pr("  sum words+reads+mfma c0", med([&](const uint64_t* q) { return (double)q[5]; }));
+            pr("  sum rendezvous", med([&](const uint64_t* q) { return (double)q[6]; }));
+            pr("  sum gather+c1+writeback", med([&](const uint64_t* q) { return (double)q[7]; }));
+            pr("wave lifetime", med([&](const uint64_t* q) { return (double)(q[4] - q[0]); }));
+            pr("end offset", med([&](const uint64_t* q) { return (double)(q[4] - first); }));
+            return BSMR_OK;
+        }
+        hipLaunchKernelGGL(kernel, dim3(t.numItems, g_batch.count), dim3(bsmr::kThreads), lds, s, A16, B16, t.groupRows,
+                           t.blockCols, reinterpret_cast<const uint4*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P, numCols, g_batch,
+                           (uint64_t*)nullptr);
+#else
         hipLaunchKernelGGL(kernel, dim3(t.numItems, g_batch.count), dim3(bsmr::kThreads), lds, s, A16, B16, t.groupRows,
                            t.blockCols, reinterpret_cast<const uint4*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P, numCols, g_batch);
+#endif
         BSMR_HIP(hipGetLastError());
         return BSMR_OK;
     }
