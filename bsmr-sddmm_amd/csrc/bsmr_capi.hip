@@ -102,6 +102,7 @@ struct bsmr_plan {
     bool sparseFree = false;
     uint64_t foldedEntries = 0;    // entries of a small dense part that were moved to the residue
     uint64_t promotedEntries = 0;  // residue entries of the RPHM that the plan computes as extra dense blocks
+    float buildMs[5] = {0, 0, 0, 0, 0};  // bsmr_plan_build_times: rules, packing, upload, second format, total
     bool convertPass = false;      // F16/BF16 calls start with the fp32 -> 16-bit pass over A and B
     bool convertBOnly = false;     // no dense part: calls with enough work convert B alone, the residue rounds A while staging
     uint64_t bOnlyWork = 0;        // ... residue entries x K from which that pays
@@ -131,8 +132,14 @@ namespace {
 constexpr uint64_t kGroupedGatherBytes = 400ull << 20;
 
 thread_local std::string g_lastHipError;
-// batch of the call being launched on this thread (bsmr_sddmm_batch sets it for the duration of the call)
-thread_local bsmr::Batch g_batch{0, 0, 0, 1};
+// Where a launch goes: the stream and, for a batched call, the strides between the problems of the batch (grid y).
+struct Queue {
+    hipStream_t stream = nullptr;
+    bsmr::Batch batch{0, 0, 0, 1};
+    Queue(hipStream_t s) : stream(s) {}
+    Queue(hipStream_t s, const bsmr::Batch& b) : stream(s), batch(b) {}
+    operator hipStream_t() const { return stream; }
+};
 
 inline bool hipOk(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
@@ -260,7 +267,7 @@ const DenseFormat& chooseFormat(const bsmr_plan* p, uint32_t K) {
 // --- launchers -------------------------------------------------------------
 template <int MODE>
 int launchConvert(const bsmr_plan* p, uint32_t K, const float* A, const float* B, uint16_t* A16,
-                  uint16_t* B16, hipStream_t s, bool skipA = false) {
+                  uint16_t* B16, const Queue& s, bool skipA = false) {
     const uint64_t nA8 = skipA ? 0 : (uint64_t)p->M * K / 8, nB8 = (uint64_t)p->N * K / 8;
     const uint64_t total = nA8 + nB8;
     if (total == 0) return BSMR_OK;
@@ -279,13 +286,13 @@ int launchConvert(const bsmr_plan* p, uint32_t K, const float* A, const float* B
 // per workgroup batch) are compile-time.  LDS = 2 * NB * KS KiB.
 template <int KS, int H, int NB, int MODE, typename TileT, bool LDS_STAGE = false>
 int launchGroupsT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, const TileT* tiles, float* P,
-                  hipStream_t s) {
+                  const Queue& s) {
     auto kernel = bsmr::denseGroups<KS, H, NB, MODE, TileT, LDS_STAGE>;
     // double-buffered batch of NB blocks (+ one 256-float window per group row when staged in LDS)
     const size_t lds = (size_t)2 * NB * 1024u * KS + (LDS_STAGE ? (size_t)H * 16u * 1024u : 0u);
     if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, currentDevice())) return st;
-    hipLaunchKernelGGL(kernel, dim3(f.numItems, g_batch.count), dim3(bsmr::kThreads), lds, s, A16, B16, f.groupRows, f.rowBase,
-                       f.winLen, f.winMask, f.blockCols, tiles, f.blockMask, f.items, P, g_batch);
+    hipLaunchKernelGGL(kernel, dim3(f.numItems, s.batch.count), dim3(bsmr::kThreads), lds, s, A16, B16, f.groupRows, f.rowBase,
+                       f.winLen, f.winMask, f.blockCols, tiles, f.blockMask, f.items, P, s.batch);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -293,7 +300,7 @@ int launchGroupsT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
 // streaming form for ungrouped plans whose items hold <= 32 blocks (8 per wave)
 template <int KS, int MODE, typename TileT, int WAVES = bsmr::kWavesPerWG, int H = 1>
 int launchStreamT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, const TileT* tiles, float* P,
-                  hipStream_t s) {
+                  const Queue& s) {
     if (WAVES == bsmr::kWavesPerWG && f.streamWaves == 1) {
         if (f.H == 2) return launchStreamT<KS, MODE, TileT, 1, 2>(f, A16, B16, tiles, P, s);
         return launchStreamT<KS, MODE, TileT, 1, 1>(f, A16, B16, tiles, P, s);
@@ -301,14 +308,14 @@ int launchStreamT(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
     auto kernel = bsmr::denseStream<KS, MODE, TileT, 8, WAVES, H>;
     const size_t lds = (size_t)WAVES * bsmr::streamSlots(KS) * 1024u * (KS > 8 ? 8 : KS);  // wave-private ring of images
     if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, currentDevice())) return st;
-    hipLaunchKernelGGL(kernel, dim3(f.numItems, g_batch.count), dim3(WAVES * bsmr::kWave), lds, s, A16, B16, f.groupRows, f.rowBase,
-                       f.blockCols, tiles, f.items, P, g_batch);
+    hipLaunchKernelGGL(kernel, dim3(f.numItems, s.batch.count), dim3(WAVES * bsmr::kWave), lds, s, A16, B16, f.groupRows, f.rowBase,
+                       f.blockCols, tiles, f.items, P, s.batch);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
 
 template <int KS, int MODE>
-int launchStream(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+int launchStream(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, const Queue& s) {
     if (f.tilesM) return launchStreamT<KS, MODE, bsmr::TileMask>(f, A16, B16, f.tilesM, P, s);
     if (f.tiles8) return launchStreamT<KS, MODE, uint8_t>(f, A16, B16, f.tiles8, P, s);
     return f.tiles16 ? launchStreamT<KS, MODE, uint16_t>(f, A16, B16, f.tiles16, P, s)
@@ -316,7 +323,7 @@ int launchStream(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16,
 }
 
 template <int KS, int H, int NB, int MODE>
-int launchGroups(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+int launchGroups(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, const Queue& s) {
     if (f.tilesM) return launchGroupsT<KS, H, NB, MODE, bsmr::TileMask, false>(f, A16, B16, f.tilesM, P, s);
     if (f.tiles8)
         return f.stageInLds ? launchGroupsT<KS, H, NB, MODE, uint8_t, true>(f, A16, B16, f.tiles8, P, s)
@@ -326,7 +333,7 @@ int launchGroups(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16,
 }
 
 template <int KS, int NB, int MODE>
-int launchGroupsH(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+int launchGroupsH(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16, float* P, const Queue& s) {
     switch (f.H) {
     case 1: return launchGroups<KS, 1, NB, MODE>(f, A16, B16, P, s);
     case 2: return launchGroups<KS, 2, NB, MODE>(f, A16, B16, P, s);
@@ -425,7 +432,7 @@ int ensureTiles(bsmr_plan* p, uint32_t H) {
 }
 
 template <int KS, int H, int MODE, int DEPTH>
-int launchTilesD(const TileFormatDev& t, int device, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+int launchTilesD(const TileFormatDev& t, int device, const uint16_t* A16, const uint16_t* B16, float* P, const Queue& s) {
     auto kernel = bsmr::denseTiles<KS, H, MODE, DEPTH>;
     const size_t lds = bsmr::tileLdsBytes(KS, H, DEPTH, t.entryCap);
     if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, device)) return st;
@@ -437,7 +444,7 @@ int launchTilesD(const TileFormatDev& t, int device, const uint16_t* A16, const 
         BSMR_HIP(hipMemset(dev, 0, n * 8));
         hipLaunchKernelGGL(kernel, dim3(t.numItems, 1), dim3(bsmr::kWave), lds, s, A16, B16, t.groupRows, t.blockCols,
                            reinterpret_cast<const uint4*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P, t.entryCap,
-                           g_batch, dev);
+                           s.batch, dev);
         BSMR_HIP(hipStreamSynchronize(s));
         std::vector<uint64_t> h(n);
         BSMR_HIP(hipMemcpy(h.data(), dev, n * 8, hipMemcpyDeviceToHost));
@@ -467,20 +474,20 @@ int launchTilesD(const TileFormatDev& t, int device, const uint16_t* A16, const 
         pr("wave lifetime", med([&](const uint64_t* q) { return (double)(q[4] - q[0]); }));
         return BSMR_OK;
     }
-    hipLaunchKernelGGL(kernel, dim3(t.numItems, g_batch.count), dim3(bsmr::kWave), lds, s, A16, B16, t.groupRows,
+    hipLaunchKernelGGL(kernel, dim3(t.numItems, s.batch.count), dim3(bsmr::kWave), lds, s, A16, B16, t.groupRows,
                        t.blockCols, reinterpret_cast<const uint4*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P,
-                       t.entryCap, g_batch, (uint64_t*)nullptr);
+                       t.entryCap, s.batch, (uint64_t*)nullptr);
 #else
-    hipLaunchKernelGGL(kernel, dim3(t.numItems, g_batch.count), dim3(bsmr::kWave), lds, s, A16, B16, t.groupRows,
+    hipLaunchKernelGGL(kernel, dim3(t.numItems, s.batch.count), dim3(bsmr::kWave), lds, s, A16, B16, t.groupRows,
                        t.blockCols, reinterpret_cast<const uint4*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P,
-                       t.entryCap, g_batch);
+                       t.entryCap, s.batch);
 #endif
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
 
 template <int KS, int H, int MODE>
-int launchTilesT(const TileFormatDev& t, int device, int depth, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+int launchTilesT(const TileFormatDev& t, int device, int depth, const uint16_t* A16, const uint16_t* B16, float* P, const Queue& s) {
     if constexpr (KS * H > 32) {
         return BSMR_ERR_INVALID_ARG;
     } else {
@@ -491,7 +498,7 @@ int launchTilesT(const TileFormatDev& t, int device, int depth, const uint16_t* 
 }
 
 template <int KS, int MODE>
-int launchTilesH(const TileFormatDev& t, int device, int depth, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+int launchTilesH(const TileFormatDev& t, int device, int depth, const uint16_t* A16, const uint16_t* B16, float* P, const Queue& s) {
     switch (t.H) {
     case 1: return launchTilesT<KS, 1, MODE>(t, device, depth, A16, B16, P, s);
     case 2: return launchTilesT<KS, 2, MODE>(t, device, depth, A16, B16, P, s);
@@ -501,7 +508,7 @@ int launchTilesH(const TileFormatDev& t, int device, int depth, const uint16_t* 
 }
 
 template <int KS, int HW, int MODE>
-int launchSharedT(const TileFormatDev& t, int device, uint32_t numCols, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+int launchSharedT(const TileFormatDev& t, int device, uint32_t numCols, const uint16_t* A16, const uint16_t* B16, float* P, const Queue& s) {
     if constexpr (KS * HW > 32) {
         return BSMR_ERR_INVALID_ARG;
     } else {
@@ -515,7 +522,7 @@ int launchSharedT(const TileFormatDev& t, int device, uint32_t numCols, const ui
             BSMR_HIP(hipMalloc(reinterpret_cast<void**>(&dev), n * 8));
             BSMR_HIP(hipMemset(dev, 0, n * 8));
             hipLaunchKernelGGL(kernel, dim3(t.numItems, 1), dim3(bsmr::kThreads), lds, s, A16, B16, t.groupRows, t.blockCols,
-                               reinterpret_cast<const uint4*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P, numCols, g_batch, dev);
+                               reinterpret_cast<const uint4*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P, numCols, s.batch, dev);
             BSMR_HIP(hipStreamSynchronize(s));
             std::vector<uint64_t> h(n);
             BSMR_HIP(hipMemcpy(h.data(), dev, n * 8, hipMemcpyDeviceToHost));
@@ -542,12 +549,12 @@ int launchSharedT(const TileFormatDev& t, int device, uint32_t numCols, const ui
             pr("end offset", med([&](const uint64_t* q) { return (double)(q[4] - first); }));
             return BSMR_OK;
         }
-        hipLaunchKernelGGL(kernel, dim3(t.numItems, g_batch.count), dim3(bsmr::kThreads), lds, s, A16, B16, t.groupRows,
-                           t.blockCols, reinterpret_cast<const uint4*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P, numCols, g_batch,
+        hipLaunchKernelGGL(kernel, dim3(t.numItems, s.batch.count), dim3(bsmr::kThreads), lds, s, A16, B16, t.groupRows,
+                           t.blockCols, reinterpret_cast<const uint4*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P, numCols, s.batch,
                            (uint64_t*)nullptr);
 #else
-        hipLaunchKernelGGL(kernel, dim3(t.numItems, g_batch.count), dim3(bsmr::kThreads), lds, s, A16, B16, t.groupRows,
-                           t.blockCols, reinterpret_cast<const uint4*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P, numCols, g_batch);
+        hipLaunchKernelGGL(kernel, dim3(t.numItems, s.batch.count), dim3(bsmr::kThreads), lds, s, A16, B16, t.groupRows,
+                           t.blockCols, reinterpret_cast<const uint4*>(t.blockInfo), t.entries, t.items, t.itemRowBase, P, numCols, s.batch);
 #endif
         BSMR_HIP(hipGetLastError());
         return BSMR_OK;
@@ -555,7 +562,7 @@ int launchSharedT(const TileFormatDev& t, int device, uint32_t numCols, const ui
 }
 
 template <int KS, int MODE>
-int launchSharedH(const TileFormatDev& t, int device, uint32_t numCols, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+int launchSharedH(const TileFormatDev& t, int device, uint32_t numCols, const uint16_t* A16, const uint16_t* B16, float* P, const Queue& s) {
     switch (t.H) {
     case 4: return launchSharedT<KS, 1, MODE>(t, device, numCols, A16, B16, P, s);
     case 8: return launchSharedT<KS, 2, MODE>(t, device, numCols, A16, B16, P, s);
@@ -564,7 +571,7 @@ int launchSharedH(const TileFormatDev& t, int device, uint32_t numCols, const ui
 }
 
 template <int MODE>
-int launchTiles(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P, hipStream_t s) {
+int launchTiles(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P, const Queue& s) {
     const TileFormatDev& t = p->tiles[tileSlot(chooseTileGroup(p, K))];
     if (!t.H) return BSMR_ERR_INVALID_ARG;   // ensureTiles runs before every launch path
     if (t.numItems == 0) return BSMR_OK;
@@ -592,7 +599,7 @@ inline bool tilesEngine(const bsmr_plan* p, uint32_t K) {
 
 template <int MODE>
 int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
-                  hipStream_t s) {
+                  const Queue& s) {
     if (tilesEngine(p, K)) return launchTiles<MODE>(p, K, A16, B16, P, s);
     const DenseFormat& f = chooseFormat(p, K);
     if (f.numItems == 0) return BSMR_OK;
@@ -617,64 +624,64 @@ int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uin
     }
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
     if (f.tilesM)
-        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, bsmr::TileMask>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A16,
+        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, bsmr::TileMask>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A16,
                            B16, K, f.H, f.groupRows, f.rowBase, f.blockCols, f.tilesM, f.blockMask, f.items,
-                           f.numItems, P, g_batch);
+                           f.numItems, P, s.batch);
     else if (f.tiles8)
-        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint8_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A16,
+        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint8_t>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A16,
                            B16, K, f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items,
-                           f.numItems, P, g_batch);
+                           f.numItems, P, s.batch);
     else if (f.tiles16)
-        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint16_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A16,
+        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint16_t>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A16,
                            B16, K, f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items,
-                           f.numItems, P, g_batch);
+                           f.numItems, P, s.batch);
     else
-        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint32_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A16,
+        hipLaunchKernelGGL((bsmr::denseGroupsAnyK<MODE, uint32_t>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A16,
                            B16, K, f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items,
-                           f.numItems, P, g_batch);
+                           f.numItems, P, s.batch);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
 
 // fp32 operands, rounded to fp16 / bf16 in registers (small dense parts)
 template <int MODE>
-int launchDenseCvt(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, hipStream_t s) {
+int launchDenseCvt(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, const Queue& s) {
     const DenseFormat& f = p->fmt[0];
     if (f.numItems == 0) return BSMR_OK;
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
     if (f.tilesM)
-        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, bsmr::TileMask>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tilesM, f.blockMask, f.items, f.numItems, P, g_batch);
+        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, bsmr::TileMask>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tilesM, f.blockMask, f.items, f.numItems, P, s.batch);
     else if (f.tiles8)
-        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint8_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items, f.numItems, P, g_batch);
+        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint8_t>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items, f.numItems, P, s.batch);
     else if (f.tiles16)
-        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint16_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items, f.numItems, P, g_batch);
+        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint16_t>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items, f.numItems, P, s.batch);
     else
-        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint32_t>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
-                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items, f.numItems, P, g_batch);
+        hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, uint32_t>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
+                           f.H, f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items, f.numItems, P, s.batch);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
 
 int launchDense32(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P,
-                  hipStream_t s) {
+                  const Queue& s) {
     const DenseFormat& f = p->fmt[0];
     if (f.numItems == 0) return BSMR_OK;
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
     if (f.tilesM)
-        hipLaunchKernelGGL(bsmr::denseGroupsF32<bsmr::TileMask>, dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
-                           f.groupRows, f.rowBase, f.blockCols, f.tilesM, f.blockMask, f.items, f.numItems, P, g_batch);
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<bsmr::TileMask>, dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
+                           f.groupRows, f.rowBase, f.blockCols, f.tilesM, f.blockMask, f.items, f.numItems, P, s.batch);
     else if (f.tiles8)
-        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint8_t>, dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
-                           f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items, f.numItems, P, g_batch);
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint8_t>, dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
+                           f.groupRows, f.rowBase, f.blockCols, f.tiles8, f.blockMask, f.items, f.numItems, P, s.batch);
     else if (f.tiles16)
-        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint16_t>, dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
-                           f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items, f.numItems, P, g_batch);
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint16_t>, dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
+                           f.groupRows, f.rowBase, f.blockCols, f.tiles16, f.blockMask, f.items, f.numItems, P, s.batch);
     else
-        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint32_t>, dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
-                           f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items, f.numItems, P, g_batch);
+        hipLaunchKernelGGL(bsmr::denseGroupsF32<uint32_t>, dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A, B, K, f.H,
+                           f.groupRows, f.rowBase, f.blockCols, f.tiles32, f.blockMask, f.items, f.numItems, P, s.batch);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -699,24 +706,24 @@ SparseShape sparseShape(const bsmr_plan* p, uint32_t K, bool lowp) {
 }
 
 template <int LPE, int CPL>
-int launchSparseT(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, hipStream_t s) {
+int launchSparseT(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, const Queue& s) {
     const size_t lds = (size_t)16 * (K + bsmr::kSparseLdsPad) * sizeof(float);
     const uint32_t wgs = p->numSparseItems;  // no padding: every workgroup reads its item
     if (p->sparseFree) {
-        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, false, CPL, true>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s,
-                           A, B, K, p->entryRowId, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, g_batch);
+        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, false, CPL, true>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s,
+                           A, B, K, p->entryRowId, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, s.batch);
     } else if (lds <= 64 * 1024) {
-        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, true, CPL>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), lds, s, A, B,
-                           K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, g_batch);
+        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, true, CPL>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), lds, s, A, B,
+                           K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, s.batch);
     } else {
-        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, false, CPL>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s, A, B,
-                           K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, g_batch);
+        hipLaunchKernelGGL((bsmr::sparseEntries<LPE, false, CPL>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A, B,
+                           K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, s.batch);
     }
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
 
-int launchSparse(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, hipStream_t s) {
+int launchSparse(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, const Queue& s) {
     if (p->numSparseItems == 0) return BSMR_OK;
     const SparseShape sh = sparseShape(p, K, false);
     switch (sh.lpe * 100 + sh.cpl) {
@@ -733,23 +740,23 @@ int launchSparse(const bsmr_plan* p, uint32_t K, const float* A, const float* B,
 
 template <int LPE, int CPL, int MODE>
 int launchSparse16T(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
-                    hipStream_t s, bool aFp32) {
+                    const Queue& s, bool aFp32) {
     const size_t lds = (size_t)16 * (2u * K + bsmr::kSparseLdsPad16);
     const uint32_t wgs = p->numSparseItems;
     if (aFp32) {  // only set when the panels fit LDS and the residue is in panel form
-        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, true, CPL, false, true>), dim3(wgs, g_batch.count),
+        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, true, CPL, false, true>), dim3(wgs, s.batch.count),
                            dim3(bsmr::kThreads), lds, s, A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow,
-                           p->sparseItems, P, g_batch);
+                           p->sparseItems, P, s.batch);
     } else if (p->sparseFree) {
-        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, false, CPL, true>), dim3(wgs, g_batch.count),
+        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, false, CPL, true>), dim3(wgs, s.batch.count),
                            dim3(bsmr::kThreads), 0, s, A16, B16, K, p->entryRowId, p->entryCol, p->entryDst, p->entryRow,
-                           p->sparseItems, P, g_batch);
+                           p->sparseItems, P, s.batch);
     } else if (lds <= 64 * 1024) {
-        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, true, CPL>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), lds, s,
-                           A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, g_batch);
+        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, true, CPL>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), lds, s,
+                           A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, s.batch);
     } else {
-        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, false, CPL>), dim3(wgs, g_batch.count), dim3(bsmr::kThreads), 0, s,
-                           A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, g_batch);
+        hipLaunchKernelGGL((bsmr::sparseEntriesLowp<LPE, MODE, false, CPL>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s,
+                           A16, B16, K, p->panelRows, p->entryCol, p->entryDst, p->entryRow, p->sparseItems, P, s.batch);
     }
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
@@ -758,7 +765,7 @@ int launchSparse16T(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const u
 // aFp32: A16 is the caller's fp32 A (plans that convert B alone)
 template <int MODE>
 int launchSparse16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
-                   hipStream_t s, bool aFp32 = false) {
+                   const Queue& s, bool aFp32 = false) {
     if (p->numSparseItems == 0) return BSMR_OK;
     const SparseShape sh = sparseShape(p, K, true);
     switch (sh.lpe * 100 + sh.cpl) {
@@ -784,17 +791,17 @@ int checkCall(const bsmr_plan* p, uint32_t K, const void* A, const void* B, cons
 
 // all-sparse plan, residue entries x K large enough to repay a conversion pass over B (and the kernel boundary
 // after it): B alone is converted and the residue kernel rounds A's rows while it stages them in LDS
-inline bool convertsBOnly(const bsmr_plan* p, uint32_t K) {
+inline bool convertsBOnly(const bsmr_plan* p, uint32_t K, uint32_t batches = 1) {
     if (!p->convertBOnly || (size_t)16 * (2u * K + bsmr::kSparseLdsPad16) > 64 * 1024) return false;
-    const uint64_t work = (uint64_t)p->numSparseEntries * K * g_batch.count;
+    const uint64_t work = (uint64_t)p->numSparseEntries * K * batches;
     // the pass costs ~N*K, the halved gather saves ~entries*K: patterns with >= 11 entries per column repay it from
     // a third of the work (Trefethen_20000, 14 per column: K=128 15.3 -> 14.3 us, K=256 24.1 -> 22.0; wathen100,
     // 8 per column: K=128 10.9 -> 12.9, K=256 20.5 -> 24.0 when forced, K=512 38.2 -> 36.8)
     return work >= p->bOnlyWork || (p->numSparseEntries >= 11ull * p->N && work * 10 >= p->bOnlyWork * 3);
 }
 
-inline bool needsWorkspace(const bsmr_plan* p, int mode, uint32_t K) {
-    return mode != BSMR_COMPUTE_F32 && (p->convertPass || convertsBOnly(p, K));
+inline bool needsWorkspace(const bsmr_plan* p, int mode, uint32_t K, uint32_t batches = 1) {
+    return mode != BSMR_COMPUTE_F32 && (p->convertPass || convertsBOnly(p, K, batches));
 }
 
 // device format of the dense part for calls with inner dimension K (allocates on first use)
@@ -817,7 +824,7 @@ int reserve(bsmr_plan* p, uint32_t K) {
 }
 
 // which: bit 0 convert, bit 1 dense, bit 2 sparse
-int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, int mode, hipStream_t s,
+int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, int mode, const Queue& s,
               int which) {
     const bool f16 = mode == BSMR_COMPUTE_F16;
     const bool hasDense = p->fmt[0].numItems != 0 || p->hostDense.entries() != 0;
@@ -827,7 +834,7 @@ int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P
     bool convertAll = false, convertB = false;
     if (mode == BSMR_COMPUTE_F32) {
         dense = kDense32;
-    } else if (convertsBOnly(p, K)) {
+    } else if (convertsBOnly(p, K, s.batch.count)) {
         convertB = true;
         sparse = kSparse16FromFp32A;
     } else if (p->convertInKernel) {
@@ -843,7 +850,7 @@ int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P
         st = f16 ? launchConvert<0>(p, K, A, B, p->A16, p->B16, s, convertB) : launchConvert<1>(p, K, A, B, p->A16, p->B16, s, convertB);
         if (st != BSMR_OK) return st;
     }
-    auto runDense = [&](hipStream_t q) -> int {
+    auto runDense = [&](const Queue& q) -> int {
         switch (dense) {
         case kDense32: return launchDense32(p, K, A, B, P, q);
         case kDenseCvt: return f16 ? launchDenseCvt<0>(p, K, A, B, P, q) : launchDenseCvt<1>(p, K, A, B, P, q);
@@ -851,7 +858,7 @@ int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P
         default: return BSMR_OK;
         }
     };
-    auto runSparse = [&](hipStream_t q) -> int {
+    auto runSparse = [&](const Queue& q) -> int {
         switch (sparse) {
         case kSparse16: return f16 ? launchSparse16<0>(p, K, p->A16, p->B16, P, q) : launchSparse16<1>(p, K, p->A16, p->B16, P, q);
         case kSparse16FromFp32A:
@@ -866,7 +873,7 @@ int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P
         // the caller's stream.  Entries are disjoint, operands read-only: no ordering between the two is needed.
         BSMR_HIP(hipEventRecord(p->forkEvent, s));
         BSMR_HIP(hipStreamWaitEvent(p->sideStream, p->forkEvent, 0));
-        if ((st = runSparse(p->sideStream)) != BSMR_OK) return st;
+        if ((st = runSparse(Queue(p->sideStream, s.batch))) != BSMR_OK) return st;
         BSMR_HIP(hipEventRecord(p->joinEvent, p->sideStream));
         if ((st = runDense(s)) != BSMR_OK) return st;
         BSMR_HIP(hipStreamWaitEvent(s, p->joinEvent, 0));
@@ -1067,6 +1074,9 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
     if (st != BSMR_OK) return st;
 
     try {
+        typedef std::chrono::steady_clock Clock;
+        const Clock::time_point tStart = Clock::now();
+        auto msSince = [](Clock::time_point t) { return std::chrono::duration<float, std::milli>(Clock::now() - t).count(); };
         // A dense part of a few thousand entries costs more as its own launch (>= 3-5 us) than as part of
         // the residue (wathen100 K=128, 195 blocks / 15 805 entries: 17.4 -> 12.2 us; cop20k-like, 6 blocks:
         // 108 -> 101 us): fold it into the residue.  The entries and their destinations are unchanged.
@@ -1167,9 +1177,12 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         // 9.3 -> 10.1 us, mycielskian15 34.9 -> 36.2) and wins once they do not (reddit-like shard, 119 MB of tiles:
         // 317 -> 295 us).  -1 = by that size; (mode 2 assembles the 8-bit windows in LDS)
         opt.maskTiles = outputMode == 1 && (o.mask_tiles > 0 || (o.mask_tiles < 0 && (uint64_t)d->block_offsets[P] * 256ull > (32ull << 20)));
+        const float rulesMs = msSince(tStart);
+        const Clock::time_point tPack = Clock::now();
         bsmr::PackedPlan pk;
         st = bsmr::packPlan(d, opt, pk);
         if (st != BSMR_OK) return st;
+        const float packMs = msSince(tPack);
 
         bsmr_plan* p = new (std::nothrow) bsmr_plan;
         if (!p) return BSMR_ERR_OOM;
@@ -1217,6 +1230,7 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         p->convertBOnly = cvt < 0 && p->sparseLowp && pk.numBlocks == 0 && !pk.freeResidue && pk.numSparseEntries != 0 &&
                           o.b_only != 0;
 
+        const Clock::time_point tUpload = Clock::now();
         st = uploadDense(p->fmt[0], pk, p->indexBytes);
         p->fmt[0].stageInLds = outputMode == 2;
         p->fmt[0].streamWaves = streamWaves == 1 && p->fmt[0].maxItemBlocks <= 8 ? 1 : 4;
@@ -1240,6 +1254,10 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
                 st = BSMR_ERR_HIP;
             p->overlap = st == BSMR_OK;
         }
+        p->buildMs[0] = rulesMs;
+        p->buildMs[1] = packMs;
+        p->buildMs[2] = msSince(tUpload);
+        const Clock::time_point tSecond = Clock::now();
         // second dense format (4 panels per group) for gather-bound calls
         // (only when it could ever be chosen: chooseFormat wants the ungrouped columns cut 2.5x)
         if (st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8 &&
@@ -1257,6 +1275,8 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
             delete p;
             return st;
         }
+        p->buildMs[3] = msSince(tSecond);
+        p->buildMs[4] = msSince(tStart);
         *out = p;
         return BSMR_OK;
     } catch (const std::bad_alloc&) {
@@ -1271,6 +1291,16 @@ int bsmr_plan_destroy(bsmr_plan* plan) {
     if (hipSetDevice(plan->device) != hipSuccess) (void)hipGetLastError();
     freePlanDevice(plan);
     delete plan;
+    return BSMR_OK;
+}
+
+int bsmr_plan_build_times(const bsmr_plan* p, bsmr_plan_build_ms* out) {
+    if (!p || !out) return BSMR_ERR_INVALID_ARG;
+    out->rules_ms = p->buildMs[0];
+    out->pack_ms = p->buildMs[1];
+    out->upload_ms = p->buildMs[2];
+    out->second_format_ms = p->buildMs[3];
+    out->total_ms = p->buildMs[4];
     return BSMR_OK;
 }
 
@@ -1364,19 +1394,15 @@ int bsmr_sddmm_batch(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     if (num_batches == 0) return BSMR_OK;
     if (num_batches > 65535u || (uint64_t)K * num_batches > 0xFFFFFFFFull) return BSMR_ERR_INVALID_ARG;
     BSMR_HIP(hipSetDevice(plan->device));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    struct Restore {
-        ~Restore() { g_batch = bsmr::Batch{0, 0, 0, 1}; }
-    } restore;
-    g_batch = bsmr::Batch{(uint64_t)plan->M * K, (uint64_t)plan->N * K, plan->nnz, num_batches};
+    const Queue s(static_cast<hipStream_t>(stream), bsmr::Batch{(uint64_t)plan->M * K, (uint64_t)plan->N * K, plan->nnz, num_batches});
     if (mode != BSMR_COMPUTE_F32 && (st = prepareDense(plan, K)) != BSMR_OK) return st;
-    if (needsWorkspace(plan, mode, K)) {
+    if (needsWorkspace(plan, mode, K, num_batches)) {
         // the batches are contiguous, so one conversion pass covers all of them
         if ((st = reserve(plan, K * num_batches)) != BSMR_OK) return st;
-        const bool skipA = convertsBOnly(plan, K);
+        const bool skipA = convertsBOnly(plan, K, num_batches);
         st = mode == BSMR_COMPUTE_F16
-                 ? launchConvert<0>(plan, K * num_batches, A, B, plan->A16, plan->B16, s, skipA)
-                 : launchConvert<1>(plan, K * num_batches, A, B, plan->A16, plan->B16, s, skipA);
+                 ? launchConvert<0>(plan, K * num_batches, A, B, plan->A16, plan->B16, Queue(s.stream), skipA)
+                 : launchConvert<1>(plan, K * num_batches, A, B, plan->A16, plan->B16, Queue(s.stream), skipA);
         if (st != BSMR_OK) return st;
     }
     return runPieces(plan, K, A, B, P, mode, s, 6);  // dense + residue, grid y = batch

@@ -361,15 +361,28 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
     out.staged = opt.staged && !opt.forceWideTiles;
     std::vector<uint32_t> itemLo;  // STAGED: [items*R] window base per item row (kNone = unused)
     if (out.staged) {
+      // groups are independent: every worker cuts the items of a contiguous range of groups, the ranges are
+      // concatenated in group order afterwards
+      const size_t ranges = std::max<size_t>(1, std::min<size_t>(packThreads(), G / 8));
+      std::vector<std::vector<DenseItem>> rangeItems(ranges);
+      std::vector<std::vector<uint32_t>> rangeLo(ranges);
+      std::vector<uint8_t> rangeTooWide(ranges, 0);
+      const size_t perRange = (G + ranges - 1) / ranges;
+      parallelChunks(ranges, 1, [&](size_t r0, size_t r1, size_t) {
+       for (size_t range = r0; range < r1; ++range) {
+        std::vector<DenseItem>& myItems = rangeItems[range];
+        std::vector<uint32_t>& myLo = rangeLo[range];
+        bool staged = true;
         std::vector<uint32_t> lo(R), hi(R), blo(R), bhi(R);
-        for (uint32_t gi = 0; gi < G && out.staged; ++gi) {
+        const uint32_t gEnd = (uint32_t)std::min<size_t>(G, (range + 1) * perRange);
+        for (uint32_t gi = (uint32_t)(range * perRange); gi < gEnd && staged; ++gi) {
             uint32_t itemFirst = groupFirstBlock[gi], count = 0;
             std::fill(lo.begin(), lo.end(), kNone);
             std::fill(hi.begin(), hi.end(), 0u);
             auto closeItem = [&]() {
                 if (!count) return;
-                out.denseItems.push_back(DenseItem{gi, itemFirst, count, 0});
-                itemLo.insert(itemLo.end(), lo.begin(), lo.end());
+                myItems.push_back(DenseItem{gi, itemFirst, count, 0});
+                myLo.insert(myLo.end(), lo.begin(), lo.end());
                 std::fill(lo.begin(), lo.end(), kNone);
                 std::fill(hi.begin(), hi.end(), 0u);
                 count = 0;
@@ -388,10 +401,10 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
                 bool fits = count < perItem;
                 for (uint32_t r = 0; r < R; ++r) {
                     if (blo[r] == kNone) continue;
-                    if (bhi[r] - blo[r] >= kWindowMax) out.staged = false;  // one block alone is too wide
+                    if (bhi[r] - blo[r] >= kWindowMax) staged = false;  // one block alone is too wide
                     if (lo[r] != kNone && std::max(hi[r], bhi[r]) - std::min(lo[r], blo[r]) >= kWindowMax) fits = false;
                 }
-                if (!out.staged) break;
+                if (!staged) break;
                 if (!fits) closeItem();
                 if (count == 0) itemFirst = b;
                 for (uint32_t r = 0; r < R; ++r) {
@@ -403,6 +416,14 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
             }
             closeItem();
         }
+        rangeTooWide[range] = !staged;
+       }
+      });
+      for (size_t range = 0; range < ranges; ++range) {
+          if (rangeTooWide[range]) out.staged = false;
+          out.denseItems.insert(out.denseItems.end(), rangeItems[range].begin(), rangeItems[range].end());
+          itemLo.insert(itemLo.end(), rangeLo[range].begin(), rangeLo[range].end());
+      }
     }
     phase("items (window scan)");
     if (out.staged) {
@@ -528,9 +549,9 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
         if (d->sparse_col_indices[i] >= d->N || d->sparse_values[i] >= d->nnz ||
             d->sparse_relative_rows[i] >= 16)
             return BSMR_ERR_BAD_PLAN;
-    {
+    parallelChunks(P, 256, [&](size_t q0, size_t q1, size_t) {
         std::vector<uint64_t> keys;  // (column, position in the panel): one plain sort = stable by column
-        for (uint32_t p = 0; p < P; ++p) {
+        for (size_t p = q0; p < q1; ++p) {
             const uint32_t s0 = d->sparse_value_offsets[p], s1 = d->sparse_value_offsets[p + 1];
             keys.resize(s1 - s0);
             for (uint32_t i = 0; i < s1 - s0; ++i) keys[i] = ((uint64_t)d->sparse_col_indices[s0 + i] << 32) | i;
@@ -542,7 +563,7 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
                 out.entryRow[s0 + i] = (uint8_t)d->sparse_relative_rows[from];
             }
         }
-    }
+    });
     out.numSparseEntries = numSparse;
     phase("residue entries");
     if (out.numDenseEntries + numSparse != d->nnz) return BSMR_ERR_BAD_PLAN;

@@ -145,6 +145,7 @@ public:
     bool initializeFromMtxFile(const std::string& file);
     bool initializeFromSmtxFile(const std::string& file);
     bool initializeFromGraphDataset(const std::string& file);
+    bool initializeFromNpzFile(const std::string& file);   // graph archives of scripts/convert_mtx_to_npz.py
 
     bool outputToMarketMatrixFile(const std::string& fileName) const;
     bool outputToMarketMatrixFile() const;

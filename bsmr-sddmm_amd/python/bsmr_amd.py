@@ -43,6 +43,10 @@ class RphmDesc(C.Structure):
                 ("sparse_relative_rows", u32p), ("sparse_col_indices", u32p)]
 
 
+class PlanBuildMs(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("rules_ms", "pack_ms", "upload_ms", "second_format_ms", "total_ms")]
+
+
 class PlanStats(C.Structure):
     _fields_ = [("num_row_panels", C.c_uint32), ("num_dense_blocks", C.c_uint64),
                 ("num_dense_entries", C.c_uint64), ("num_sparse_entries", C.c_uint64),
@@ -114,6 +118,7 @@ HIP_SYMBOLS = {
     "bsmr_plan_options_from_env": (C.c_int, [C.POINTER(PlanOptions)]),
     "bsmr_plan_destroy": (C.c_int, [C.c_void_p]),
     "bsmr_plan_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
+    "bsmr_plan_build_times": (C.c_int, [C.c_void_p, C.POINTER(PlanBuildMs)]),
     "bsmr_cluster_rows": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float,
                                     C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p]),
     "bsmr_sddmm_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
@@ -367,6 +372,12 @@ class Pipeline:
         s = PlanStats()
         _check(hip().bsmr_plan_get_stats(self.plan, C.byref(s)), "bsmr_plan_get_stats")
         return {k: getattr(s, k) for k, _ in PlanStats._fields_}
+
+    def plan_build_ms(self) -> dict:
+        """Host wall time of bsmr_plan_create for this pipeline's plan (rules, packing, upload, second format, total)."""
+        t = PlanBuildMs()
+        _check(hip().bsmr_plan_build_times(self.plan, C.byref(t)), "bsmr_plan_build_times")
+        return {k: round(getattr(t, k), 3) for k, _ in PlanBuildMs._fields_}
 
     def dense_flags(self) -> np.ndarray:
         """uint8 per stored entry (CSR order): 1 = computed by the dense (MFMA) path of the plan, 0 = residue."""

@@ -18,10 +18,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <numeric>
 #include <random>
 #include <unordered_map>
 
+#include "npzReader.hpp"
 #include "util.hpp"
 
 // ---------------------------------------------------------------------------
@@ -278,6 +280,7 @@ bool sparseMatrix::CSR<T>::initializeFromMatrixFile(const std::string& file) {
     if (suffix == ".mtx" || suffix == ".mmio") return initializeFromMtxFile(file);
     if (suffix == ".smtx") return initializeFromSmtxFile(file);
     if (suffix == ".txt") return initializeFromGraphDataset(file);
+    if (suffix == ".npz") return initializeFromNpzFile(file);
     std::cerr << "Error, file format is not supported : " << file << std::endl;
     return false;
 }
@@ -537,6 +540,63 @@ bool sparseMatrix::CSR<T>::initializeFromGraphDataset(const std::string& file) {
             std::cerr << "Error, file " << file << " row or col is too big!" << std::endl;
             return false;
         }
+    }
+    std::vector<UIN> ro;
+    stableSortByRow(row_, ri, ci, va, ro);
+    UIN br = 0, bc = 0;
+    if (hasDuplicateInRows(ro, ci, &br, &bc)) {
+        fprintf(stderr, "Error, matrix has duplicate data! row:%u, col:%u\n", br, bc);
+        return false;
+    }
+    rowOffsets_.swap(ro);
+    colIndices_.swap(ci);
+    values_.swap(va);
+    return true;
+}
+
+template <typename T>
+bool sparseMatrix::CSR<T>::initializeFromNpzFile(const std::string& file) {
+    // Graph archive of the reference's scripts/convert_mtx_to_npz.py:9-41 (np.savez): src_li / dst_li are the
+    // 0-based row and column of every edge, num_nodes_src x num_nodes_dst the shape, num_edges the count.
+    // Values are not stored: the pattern gets zeros (SDDMM never reads S's values, src/host.cpp:62-73).
+    std::map<std::string, npz::Array> arrays;
+    std::string why;
+    if (!npz::readIntegerArrays(file, arrays, why)) {
+        std::cerr << "Error, file " << file << " : " << why << std::endl;
+        return false;
+    }
+    std::cout << "sparseMatrix::CSR initialize From file : " << file << std::endl;
+    auto scalar = [&](const char* name, long long& v) {
+        const auto it = arrays.find(name);
+        if (it == arrays.end() || it->second.values.size() != 1) return false;
+        v = it->second.values[0];
+        return true;
+    };
+    long long rows = 0, cols = 0, edges = 0;
+    const auto src = arrays.find("src_li"), dst = arrays.find("dst_li");
+    if (src == arrays.end() || dst == arrays.end() || !scalar("num_nodes_src", rows) || !scalar("num_nodes_dst", cols)) {
+        std::cerr << "Error, file " << file << " lacks src_li / dst_li / num_nodes_src / num_nodes_dst!" << std::endl;
+        return false;
+    }
+    if (!scalar("num_edges", edges)) edges = static_cast<long long>(src->second.values.size());
+    if (rows <= 0 || cols <= 0 || edges <= 1 || rows > 0xFFFFFFFELL || cols > 0xFFFFFFFELL || edges > 0xFFFFFFFELL ||
+        src->second.values.size() != static_cast<size_t>(edges) || dst->second.values.size() != static_cast<size_t>(edges)) {
+        std::cerr << "Error, file " << file << " has inconsistent sizes!" << std::endl;
+        return false;
+    }
+    row_ = static_cast<UIN>(rows);
+    col_ = static_cast<UIN>(cols);
+    nnz_ = static_cast<UIN>(edges);
+    std::vector<UIN> ri(nnz_), ci(nnz_);
+    std::vector<T> va(nnz_, T(0));
+    for (size_t i = 0; i < nnz_; ++i) {
+        const long long r = src->second.values[i], c = dst->second.values[i];
+        if (r < 0 || c < 0 || r >= rows || c >= cols) {
+            std::cerr << "Error, file " << file << " row or col is too big!" << std::endl;
+            return false;
+        }
+        ri[i] = static_cast<UIN>(r);
+        ci[i] = static_cast<UIN>(c);
     }
     std::vector<UIN> ro;
     stableSortByRow(row_, ri, ci, va, ro);

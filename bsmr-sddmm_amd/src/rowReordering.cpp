@@ -37,6 +37,7 @@
 // 560 and 417 ms on an RTX 4090).
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -118,6 +119,21 @@ struct RowEncodings {
     std::vector<BinCount> items;   // sorted by bin inside a row
     std::vector<UIN> dispersion;   // 0 for empty rows
     std::vector<uint32_t> squares; // sum of count^2 over the bins that count, modulo 2^32
+    // the bins that count once more, as what the O(|row|) similarity estimate reads: bin ids and
+    // y = count / |row| in double arithmetic, and their sum per row
+    // (one record per row and one per bin, so that judging a row touches two places in memory)
+    struct Counted {
+        double y;
+        UIN bin;
+    };
+    struct CountedRow {
+        size_t first;      // into `counted`
+        double sumY;
+        uint32_t n;
+        uint32_t squares;  // == squares[row]
+    };
+    std::vector<Counted> counted;
+    std::vector<CountedRow> countedRow;  // rows
     const BinCount* begin(UIN row) const { return items.data() + offsets[row]; }
     const BinCount* end(UIN row) const { return items.data() + offsets[row + 1]; }
 };
@@ -139,7 +155,7 @@ RowEncodings buildEncodings(const sparseMatrix::CSR<float>& m, const UIN binWidt
             if (b == e) continue;
             bins.clear();
             for (UIN i = b; i < e; ++i) bins.push_back(m.colIndices()[i] / binWidth);
-            std::sort(bins.begin(), bins.end());
+            if (!std::is_sorted(bins.begin(), bins.end())) std::sort(bins.begin(), bins.end());
             numBins[r] = static_cast<UIN>(std::unique(bins.begin(), bins.end()) - bins.begin());
         }
     }
@@ -155,7 +171,7 @@ RowEncodings buildEncodings(const sparseMatrix::CSR<float>& m, const UIN binWidt
             if (b == e) continue;
             bins.clear();
             for (UIN i = b; i < e; ++i) bins.push_back(m.colIndices()[i] / binWidth);
-            std::sort(bins.begin(), bins.end());
+            if (!std::is_sorted(bins.begin(), bins.end())) std::sort(bins.begin(), bins.end());
             BinCount* out = enc.items.data() + enc.offsets[r];
             uint64_t slack = 0;
             uint32_t sq = 0;
@@ -174,6 +190,31 @@ RowEncodings buildEncodings(const sparseMatrix::CSR<float>& m, const UIN binWidt
             enc.squares[r] = sq;
         }
     }
+    enc.countedRow.assign(rows, RowEncodings::CountedRow{0, 0.0, 0, 0});
+    size_t total = 0;
+    for (size_t r = 0; r < rows; ++r) {
+        uint32_t n = 0;
+        if (enc.squares[r] != 0)
+            for (const BinCount* it = enc.begin(static_cast<UIN>(r)); it != enc.end(static_cast<UIN>(r)); ++it)
+                n += sum.binCounts(it->bin);
+        enc.countedRow[r] = RowEncodings::CountedRow{total, 0.0, n, enc.squares[r]};
+        total += n;
+    }
+    enc.counted.resize(total);
+#pragma omp parallel for schedule(dynamic, 512) num_threads(util::hostThreads(omp_get_max_threads()))
+    for (long long r = 0; r < static_cast<long long>(rows); ++r) {
+        if (enc.squares[r] == 0) continue;
+        const double normRow = std::sqrt(static_cast<float>(enc.squares[r]));
+        RowEncodings::Counted* out = enc.counted.data() + enc.countedRow[r].first;
+        double sumY = 0.0;
+        for (const BinCount* it = enc.begin(static_cast<UIN>(r)); it != enc.end(static_cast<UIN>(r)); ++it) {
+            if (!sum.binCounts(it->bin)) continue;
+            const double y = static_cast<double>(it->count) / normRow;
+            *out++ = RowEncodings::Counted{y, it->bin};
+            sumY += y;
+        }
+        enc.countedRow[r].sumY = sumY;
+    }
     return enc;
 }
 
@@ -187,17 +228,25 @@ struct Representative {
     uint32_t sumSquares = 0;      // over the bins that count, modulo 2^32 (UIN accumulator of the reference)
     uint64_t totalCounted = 0;    // sum of the counts over the bins that count
     float norm = 0.0f;            // sqrtf(float(sumSquares))
-    std::vector<float> maxTree;   // per node: block sum of count/norm over the representative alone
+    std::vector<double> x;        // numBins: count / norm over the bins that count (the estimate's operand), else 0
+    double sumX = 0.0;            // totalCounted / norm
+    // per node: block sum of count/norm over the representative alone.  Only the exact evaluation reads it
+    // (a handful of pairs per matrix), so it is rebuilt on demand: tree() from any thread, once per change.
+    mutable std::vector<float> maxTree;
+    mutable std::atomic<bool> treeValid{false};
 
-    std::vector<int> touched;     // nodes of maxTree that are not zero
-    std::vector<uint32_t> stamp;  // per node, == epoch: already collected by this rebuild
-    uint32_t epoch = 0;
+    mutable std::vector<int> touched;     // nodes of maxTree that are not zero
+    mutable std::vector<uint32_t> stamp;  // per node, == epoch: already collected by this rebuild
+    mutable uint32_t epoch = 0;
 
     Representative(const BlockSum& s, size_t nb)
-        : sum(s), numBins(nb), count(nb, 0), maxTree(s.nodes(), 0.0f), stamp(s.nodes(), 0) {}
+        : sum(s), numBins(nb), count(nb, 0), x(nb, 0.0), maxTree(s.nodes(), 0.0f), stamp(s.nodes(), 0) {}
 
     void clear() {
-        for (const UIN b : bins) count[b] = 0;
+        for (const UIN b : bins) {
+            count[b] = 0;
+            x[b] = 0.0;
+        }
         bins.clear();
         sumSquares = 0;
         totalCounted = 0;
@@ -216,14 +265,31 @@ struct Representative {
             }
             count[it->bin] += it->count;
         }
-        rebuild();
+        norm = std::sqrt(static_cast<float>(sumSquares));
+        if (sumSquares != 0) {
+            const double n = norm;
+            for (const UIN b : bins)
+                if (sum.binCounts(b)) x[b] = static_cast<double>(count[b]) / n;
+            sumX = static_cast<double>(totalCounted) / n;
+        }
+        treeValid.store(false, std::memory_order_release);
+    }
+
+    const std::vector<float>& tree() const {
+        if (!treeValid.load(std::memory_order_acquire)) {
+#pragma omp critical(bsmr_representative_tree)
+            if (!treeValid.load(std::memory_order_acquire)) {
+                rebuild();
+                treeValid.store(true, std::memory_order_release);
+            }
+        }
+        return maxTree;
     }
 
     // The tree of the representative's own normalised counts.  Every value changes with the norm, but
     // only the leaves that own one of its bins, and their ancestors, are not zero: a narrow
     // representative (banded matrices: ~30 of 6 000 bins) costs its own size, not the tree's.
-    void rebuild() {
-        norm = std::sqrt(static_cast<float>(sumSquares));
+    void rebuild() const {
         const UIN T = sum.threads;
         for (const int n : touched) maxTree[n] = 0.0f;
         touched.clear();
@@ -268,6 +334,46 @@ struct Representative {
     }
 };
 
+// Set of positions with pop-min: a 64-ary tree of bit words (a priority queue of millions of cheap pushes
+// and pops cost more than the similarities it fed).
+class PositionSet {
+public:
+    explicit PositionSet(size_t n) {
+        size_t words = (n + 63) / 64;
+        for (;;) {
+            levels_.emplace_back(std::max<size_t>(words, 1), 0ull);
+            if (words <= 1) break;
+            words = (words + 63) / 64;
+        }
+    }
+    bool empty() const { return levels_.back()[0] == 0; }
+    void insert(UIN pos) {
+        size_t i = pos;
+        for (auto& level : levels_) {
+            uint64_t& w = level[i >> 6];
+            const bool wasEmpty = w == 0;
+            w |= 1ull << (i & 63);
+            if (!wasEmpty) break;
+            i >>= 6;
+        }
+    }
+    UIN popMin() {
+        size_t i = 0;
+        for (size_t l = levels_.size(); l-- > 0;) i = (i << 6) | static_cast<size_t>(__builtin_ctzll(levels_[l][i]));
+        size_t j = i;
+        for (auto& level : levels_) {
+            uint64_t& w = level[j >> 6];
+            w &= ~(1ull << (j & 63));
+            if (w != 0) break;
+            j >>= 6;
+        }
+        return static_cast<UIN>(i);
+    }
+
+private:
+    std::vector<std::vector<uint64_t>> levels_;  // [0] = one bit per position
+};
+
 // Per-thread scratch of the pair evaluation.
 struct PairScratch {
     std::vector<UIN> rowCount;                 // numBins, zero between calls
@@ -283,31 +389,44 @@ struct PairScratch {
 //   sum_b min(x_b/|x|, y_b/|y|) / sum_b max(x_b/|x|, y_b/|y|),
 // as executed by the reference (src/rowReordering.cu:235-293): only the leaves (threads)
 // that own one of the row's bins differ from the representative's cached tree.
-float similarity(const Representative& rep, const BinCount* rb, const BinCount* re, uint32_t rowSquares,
-                 PairScratch& sc, const float alpha) {
+float similarity(const Representative& rep, const RowEncodings& enc, const UIN row, PairScratch& sc, const float alpha) {
+    const RowEncodings::CountedRow& cr = enc.countedRow[row];
+    const uint32_t rowSquares = cr.squares;
     if (rep.sumSquares == 0 && rowSquares == 0) return 1.0f;
     if (rep.sumSquares == 0 || rowSquares == 0) return 0.0f;
+    // The value is only compared with alpha.  The same quotient in double arithmetic, O(|row|): with x, y the
+    // normalised counts, min + max = x + y in every bin, so  sum max = |x|_1 + |y|_1 - sum min  and only the
+    // min-sum over the row's bins has to be formed.  The fp32 block sum differs from it by a few 1e-6 at most
+    // (positive terms, < 20 roundings each), so anything further than 1e-4 from alpha is decided here; the rest
+    // goes through the exact order of operations below.
+    {
+        const double sumX = rep.sumX, sumY = cr.sumY;
+        const double a = static_cast<double>(alpha);
+        // sum min <= min(|x|_1, |y|_1) and sum max >= max(|x|_1, |y|_1): rows of a different mass are rejected unseen
+        const double bound = sumX < sumY ? sumX / sumY : sumY / sumX;
+        if (bound < a - 1e-4) return static_cast<float>(bound);
+        const RowEncodings::Counted* c = enc.counted.data() + cr.first;
+        const size_t n = cr.n;
+        const double* x = rep.x.data();
+        double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+        size_t i = 0;
+        for (; i + 4 <= n; i += 4) {
+            m0 += std::min(x[c[i].bin], c[i].y);
+            m1 += std::min(x[c[i + 1].bin], c[i + 1].y);
+            m2 += std::min(x[c[i + 2].bin], c[i + 2].y);
+            m3 += std::min(x[c[i + 3].bin], c[i + 3].y);
+        }
+        for (; i < n; ++i) m0 += std::min(x[c[i].bin], c[i].y);
+        const double minSum = (m0 + m1) + (m2 + m3);
+        const double approx = minSum / (sumX + sumY - minSum);
+        if (std::fabs(approx - a) > 1e-4) return static_cast<float>(approx);
+    }
+    const BinCount* rb = enc.begin(row);
+    const BinCount* re = enc.end(row);
     const BlockSum& sum = rep.sum;
     const UIN T = sum.threads;
     const float normRow = std::sqrt(static_cast<float>(rowSquares));
-    // The value is only compared with alpha.  The same quotient in double arithmetic, O(|row|): bins owned
-    // by the representative alone add (total - shared) / norm to the max-sum.  The fp32 block sum differs
-    // from it by a few 1e-6 at most (positive terms, < 20 roundings each), so anything further than 1e-4
-    // from alpha is decided here; the rest goes through the exact order of operations below.
-    {
-        double minSum = 0.0, maxShared = 0.0;
-        uint64_t repInRow = 0;
-        for (const BinCount* it = rb; it != re; ++it) {
-            if (!sum.binCounts(it->bin)) continue;
-            const UIN c = rep.count[it->bin];
-            const double x = static_cast<double>(c) / rep.norm, y = static_cast<double>(it->count) / normRow;
-            minSum += x < y ? x : y;
-            maxShared += x < y ? y : x;
-            repInRow += c;
-        }
-        const double approx = minSum / (maxShared + static_cast<double>(rep.totalCounted - repInRow) / rep.norm);
-        if (std::fabs(approx - static_cast<double>(alpha)) > 1e-4) return static_cast<float>(approx);
-    }
+    const std::vector<float>& repTree = rep.tree();
     if (++sc.epoch == 0) {
         std::fill(sc.stamp.begin(), sc.stamp.end(), 0u);
         sc.epoch = 1;
@@ -337,12 +456,12 @@ float similarity(const Representative& rep, const BinCount* rb, const BinCount* 
     for (const int n : sc.dirty) {
         const int a = sum.left[n], b = sum.right[n];
         const bool da = sc.stamp[a] == sc.epoch, db = sc.stamp[b] == sc.epoch;
-        sc.maxValue[n] = (da ? sc.maxValue[a] : rep.maxTree[a]) + (db ? sc.maxValue[b] : rep.maxTree[b]);
+        sc.maxValue[n] = (da ? sc.maxValue[a] : repTree[a]) + (db ? sc.maxValue[b] : repTree[b]);
         sc.minValue[n] = (da ? sc.minValue[a] : 0.0f) + (db ? sc.minValue[b] : 0.0f);
     }
     const bool touched = sc.stamp[sum.root] == sc.epoch;
     const float minSum = touched ? sc.minValue[sum.root] : 0.0f;
-    const float maxSum = touched ? sc.maxValue[sum.root] : rep.maxTree[sum.root];
+    const float maxSum = touched ? sc.maxValue[sum.root] : repTree[sum.root];
     return minSum / maxSum;
 }
 
@@ -429,23 +548,21 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
     std::vector<PairScratch> scratch;
     scratch.reserve(maxThreads);
     for (int t = 0; t < maxThreads; ++t) scratch.emplace_back(numBins, blockSum.nodes());
-    std::vector<UIN> seenBy(rows, 0);  // last cluster id that queued this position
     std::vector<UIN> newBins, pending;
-    std::priority_queue<UIN, std::vector<UIN>, std::greater<UIN>> candidates;
+    PositionSet candidates(rows);
     const bool scanEverything = !(alpha >= 0.0f);  // negative alpha accepts disjoint rows too
+    const size_t kMinChunk = static_cast<size_t>(2 * maxThreads), kMaxChunk = 1024;
+    size_t chunk = 256, sinceHit = 0;  // rows judged per parallel region of the scan path, rows judged since an acceptance
 
     // queue the unassigned positions > after of one bin; drops assigned ones for good
-    auto enqueueBin = [&](UIN bin, UIN after, UIN clusterId) {
+    auto enqueueBin = [&](UIN bin, UIN after) {
         UIN* list = invItems.data() + invOffsets[bin];
         size_t keep = 0;
         for (size_t i = 0; i < invLen[bin]; ++i) {
             const UIN pos = list[i];
             if (cluster[pos] != NULL_VALUE) continue;
             list[keep++] = pos;
-            if (pos > after && seenBy[pos] != clusterId) {
-                seenBy[pos] = clusterId;
-                candidates.push(pos);
-            }
+            if (pos > after) candidates.insert(pos);   // (everything at or before `after` has been judged)
         }
         invLen[bin] = keep;
     };
@@ -472,22 +589,28 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
             pending.clear();
             for (UIN pos = start + 1; pos < rows; ++pos)
                 if (cluster[pos] == NULL_VALUE) pending.push_back(pos);
-            constexpr size_t kChunk = 512;
+            // Rows behind the first accepted one of a chunk were judged against a representative that has
+            // changed since: wasted work.  The chunk follows the distance between acceptances (doubling while
+            // nothing is accepted), which keeps the waste near the useful work whatever the cluster sizes are.
             size_t i = 0;
             while (i < pending.size()) {
-                const size_t n = std::min(kChunk, pending.size() - i);
+                const size_t n = std::min(chunk, pending.size() - i);
                 long long firstHit = static_cast<long long>(n);
-#pragma omp parallel for schedule(static) reduction(min : firstHit) num_threads(maxThreads) if (n >= 64)
+#pragma omp parallel for schedule(static) reduction(min : firstHit) num_threads(maxThreads) if (n >= 32)
                 for (long long j = 0; j < static_cast<long long>(n); ++j) {
                     const UIN row = order[pending[i + j]];
-                    if (similarity(rep, enc.begin(row), enc.end(row), enc.squares[row],
-                                   scratch[omp_get_thread_num()], alpha) > alpha)
+                    if (similarity(rep, enc, row, scratch[omp_get_thread_num()], alpha) > alpha)
                         firstHit = std::min(firstHit, j);
                 }
                 if (firstHit == static_cast<long long>(n)) {
                     i += n;
+                    sinceHit += n;
+                    chunk = std::min<size_t>(2 * chunk, kMaxChunk);
                     continue;
                 }
+                sinceHit += static_cast<size_t>(firstHit) + 1;
+                chunk = std::min(std::max(sinceHit, kMinChunk), kMaxChunk);
+                sinceHit = 0;
                 const UIN pos = pending[i + firstHit];
                 cluster[pos] = clusterId;
                 rep.add(enc.begin(order[pos]), enc.end(order[pos]), newBins);
@@ -506,15 +629,14 @@ std::vector<UIN> bsa_rowReordering_host(const sparseMatrix::CSR<float>& matrix, 
                 zeroSquarePositions.resize(keep);
             }
         } else {
-            for (const UIN b : newBins) enqueueBin(b, start, clusterId);
+            for (const UIN b : newBins) enqueueBin(b, start);
             while (!candidates.empty()) {
-                const UIN pos = candidates.top();
-                candidates.pop();
+                const UIN pos = candidates.popMin();
                 const UIN row = order[pos];
-                if (similarity(rep, enc.begin(row), enc.end(row), enc.squares[row], scratch[0], alpha) > alpha) {
+                if (similarity(rep, enc, row, scratch[0], alpha) > alpha) {
                     cluster[pos] = clusterId;
                     rep.add(enc.begin(row), enc.end(row), newBins);
-                    for (const UIN b : newBins) enqueueBin(b, pos, clusterId);
+                    for (const UIN b : newBins) enqueueBin(b, pos);
                 }
             }
         }

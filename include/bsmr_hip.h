@@ -188,6 +188,15 @@ int bsmr_plan_create_ex(bsmr_plan **out, int device, const bsmr_rphm_desc *desc,
                         const bsmr_plan_options *options);
 int bsmr_plan_destroy(bsmr_plan *plan);
 int bsmr_plan_get_stats(const bsmr_plan *plan, bsmr_plan_stats *out);
+
+/* Host wall time bsmr_plan_create[_ex] spent, milliseconds: the plan rules (promotion, folding), packing the
+ * device format (csrc/plan_pack.hpp), allocating + uploading it, and packing + uploading the second (grouped)
+ * dense format where one is kept.  The reference has no counterpart (its RPHM constructor uploads the host
+ * arrays as they are, src/BSMR.cpp:236-262); reported so that callers can see what a re-plan costs. */
+typedef struct bsmr_plan_build_ms {
+    float rules_ms, pack_ms, upload_ms, second_format_ms, total_ms;
+} bsmr_plan_build_ms;
+int bsmr_plan_build_times(const bsmr_plan *plan, bsmr_plan_build_ms *out);
 /* Which dense format a call with inner dimension K uses (any out pointer may be NULL):
  * panels per group, MFMA tiles executed, B columns gathered. */
 int bsmr_plan_dense_choice(const bsmr_plan *plan, uint32_t K, uint32_t *group_size,

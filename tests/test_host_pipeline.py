@@ -101,6 +101,51 @@ def test_snap_edge_list_loader(engine, tmp_path):
     assert csr.col_indices.tolist() == [1, 2, 0, 3, 2]
 
 
+@pytest.mark.parametrize("compressed", [False, True])
+@pytest.mark.parametrize("index_dtype", [np.int32, np.int64])
+def test_npz_graph_loader(engine, tmp_path, compressed, index_dtype):
+    """Graph archives as the reference's scripts/convert_mtx_to_npz.py:9-41 writes them (np.savez: src_li, dst_li,
+    num_nodes_src, num_nodes_dst, num_edges); also deflated members and 64-bit indices.  Rows keep file order."""
+    rows, cols, ro, ci = synth.random_pattern(37, 53, 400, seed=12, empty_rows=3)
+    src = np.repeat(np.arange(rows), np.diff(ro)).astype(index_dtype)
+    dst = ci.astype(index_dtype)
+    perm = np.random.default_rng(5).permutation(src.size)          # edges in arbitrary order, as from a COO
+    f = tmp_path / "g.npz"
+    save = np.savez_compressed if compressed else np.savez
+    save(f, src_li=src[perm], dst_li=dst[perm], num_nodes_src=rows, num_nodes_dst=cols, num_edges=src.size)
+    csr = engine.CSR.from_file(f)
+    assert (csr.rows, csr.cols, csr.nnz) == (rows, cols, ci.size)
+    assert np.array_equal(csr.row_offsets, ro)
+    order = np.argsort(src[perm], kind="stable")                   # stable by row = the loader's contract
+    assert np.array_equal(csr.col_indices, dst[perm][order].astype(np.uint32))
+    assert not csr.values.any()
+
+
+def test_npz_graph_loader_rejects(engine, tmp_path):
+    ok = dict(src_li=np.array([0, 1, 1], np.int32), dst_li=np.array([1, 0, 2], np.int32), num_nodes_src=2,
+              num_nodes_dst=3, num_edges=3)
+    np.savez(tmp_path / "ok.npz", **ok)
+    assert engine.CSR.from_file(tmp_path / "ok.npz").nnz == 3
+    bad = {
+        "missing": {k: v for k, v in ok.items() if k != "dst_li"},
+        "range": dict(ok, src_li=np.array([0, 1, 2], np.int32)),
+        "negative": dict(ok, dst_li=np.array([1, -1, 2], np.int32)),
+        "count": dict(ok, num_edges=4),
+        "duplicate": dict(ok, src_li=np.array([0, 1, 1], np.int32), dst_li=np.array([1, 2, 2], np.int32)),
+    }
+    for name, arrays in bad.items():
+        np.savez(tmp_path / f"{name}.npz", **arrays)
+        with pytest.raises(ValueError):
+            engine.CSR.from_file(tmp_path / f"{name}.npz")
+    (tmp_path / "junk.npz").write_bytes(b"PK\x05\x06" + bytes(30))
+    with pytest.raises(ValueError):
+        engine.CSR.from_file(tmp_path / "junk.npz")
+    whole = (tmp_path / "ok.npz").read_bytes()
+    (tmp_path / "cut.npz").write_bytes(whole[: len(whole) // 2])
+    with pytest.raises(ValueError):
+        engine.CSR.from_file(tmp_path / "cut.npz")
+
+
 def test_write_then_read_mtx_roundtrip(engine, tmp_path):
     rows, cols, ro, ci = synth.random_pattern(23, 31, 150, seed=8)
     csr = engine.CSR.from_arrays(rows, cols, ro, ci)
