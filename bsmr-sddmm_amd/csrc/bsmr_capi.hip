@@ -6,6 +6,7 @@
 #include "bsmr_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -21,6 +22,7 @@
 #include <vector>
 
 #include "cluster_kernels.hpp"
+#include "pack_device.hpp"
 #include "plan_pack.hpp"
 #include "plan_promote.hpp"
 #include "sddmm_kernels.hpp"
@@ -103,6 +105,7 @@ struct bsmr_plan {
     uint64_t foldedEntries = 0;    // entries of a small dense part that were moved to the residue
     uint64_t promotedEntries = 0;  // residue entries of the RPHM that the plan computes as extra dense blocks
     float buildMs[5] = {0, 0, 0, 0, 0};  // bsmr_plan_build_times: rules, packing, upload, second format, total
+    bool packedOnDevice = false;   // fmt[0] was built by csrc/pack_device.hpp
     bool convertPass = false;      // F16/BF16 calls start with the fp32 -> 16-bit pass over A and B
     bool convertBOnly = false;     // no dense part: calls with enough work convert B alone, the residue rounds A while staging
     uint64_t bOnlyWork = 0;        // ... residue entries x K from which that pays
@@ -176,6 +179,21 @@ int upload(T*& dst, const std::vector<T>& src, uint64_t& bytes) {
     return BSMR_OK;
 }
 
+struct DeviceBuffers {
+    std::vector<void*> ptrs;
+    ~DeviceBuffers() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    bool alloc(T** out, size_t count, const char* what) {
+        void* p = nullptr;
+        if (!hipOk(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)), what)) return false;
+        ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return true;
+    }
+};
+
 int envInt(const char* name, int fallback) {
     const char* v = std::getenv(name);
     if (!v || !*v) return fallback;
@@ -248,6 +266,204 @@ int uploadDense(DenseFormat& f, const bsmr::PackedPlan& pk, uint64_t& bytes) {
     if (st == BSMR_OK) st = upload(f.blockMask, pk.blockMask, bytes);
     if (st == BSMR_OK) st = upload(f.items, pk.denseItems, bytes);
     return st;
+}
+
+
+// ---- dense format packed on the device (csrc/pack_device.hpp) ----------------------------------------------------
+struct DevicePackResult {
+    uint64_t numDenseEntries = 0, numBlocks = 0, numTiles = 0, unionColumns = 0;
+};
+constexpr int kPackOnHost = 1000;   // not a status: this input / layout is the host packer's
+
+template <typename T>
+bool keep(T*& dst, size_t count, uint64_t& bytes) {   // an array the plan keeps (counted like upload())
+    dst = nullptr;
+    if (count == 0) return true;
+    if (!hipOk(hipMalloc(reinterpret_cast<void**>(&dst), count * sizeof(T)), "hipMalloc(plan)")) return false;
+    bytes += count * sizeof(T);
+    return true;
+}
+
+void dropDense(DenseFormat& f) {
+    void* ptrs[] = {f.groupRows, f.rowBase, f.winLen, f.winMask, f.blockCols, f.tiles8, f.tilesM, f.tiles16, f.tiles32, f.blockMask, f.items};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    f = DenseFormat{};
+}
+
+// The default dense layout (one panel per group, blocks in column order, window offsets) from the RPHM arrays, on the
+// current device.  BSMR_OK: `f` is complete; kPackOnHost: nothing is kept, the host packer has to do this plan.
+int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, const std::vector<uint32_t>& panelRows, DenseFormat& f,
+                      uint64_t& indexBytes, DevicePackResult& r) {
+    const uint32_t P = d->num_row_panels;
+    const uint64_t oldBlocks = d->block_offsets[P], slots = oldBlocks * 16;
+    if (oldBlocks == 0 || slots > 0x7FFFFFFFull || P == 0) return kPackOnHost;
+    hipStream_t s = nullptr;
+    DeviceBuffers dev;   // scratch, freed on return
+    uint32_t *dCols, *dOffsets, *dValues, *dSlots, *dSlotsAlt, *dPanelCols, *dPanelBlocks, *dFirstBlock, *dFlags, *dMaxItem;
+    uint64_t *dKeys, *dKeysAlt;
+    unsigned long long* dCounters;
+    if (!dev.alloc(&dCols, slots, "hipMalloc") || !dev.alloc(&dOffsets, (size_t)P + 1, "hipMalloc") ||
+        !dev.alloc(&dValues, oldBlocks * 256, "hipMalloc") || !dev.alloc(&dKeys, slots, "hipMalloc") ||
+        !dev.alloc(&dKeysAlt, slots, "hipMalloc") || !dev.alloc(&dSlots, slots, "hipMalloc") ||
+        !dev.alloc(&dSlotsAlt, slots, "hipMalloc") || !dev.alloc(&dPanelCols, (size_t)P + 1, "hipMalloc") ||
+        !dev.alloc(&dPanelBlocks, (size_t)P + 1, "hipMalloc") || !dev.alloc(&dFirstBlock, (size_t)P + 1, "hipMalloc") ||
+        !dev.alloc(&dFlags, 1, "hipMalloc") || !dev.alloc(&dMaxItem, 1, "hipMalloc") || !dev.alloc(&dCounters, 2, "hipMalloc"))
+        return BSMR_ERR_OOM;
+    BSMR_HIP(hipMemcpyAsync(dCols, d->dense_cols, slots * 4, hipMemcpyHostToDevice, s));
+    BSMR_HIP(hipMemcpyAsync(dOffsets, d->block_offsets, ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
+    BSMR_HIP(hipMemcpyAsync(dValues, d->block_values, oldBlocks * 1024, hipMemcpyHostToDevice, s));
+    BSMR_HIP(hipMemsetAsync(dFlags, 0, 4, s));
+    BSMR_HIP(hipMemsetAsync(dMaxItem, 0, 4, s));
+    BSMR_HIP(hipMemsetAsync(dCounters, 0, 16, s));
+    hipLaunchKernelGGL(bsmr::packKeys, dim3((uint32_t)((slots + 255) / 256)), dim3(256), 0, s, dCols, dOffsets, P, slots, d->N, dKeys,
+                       dSlots, dFlags);
+    BSMR_HIP(hipGetLastError());
+    // the panels' columns in column-id order
+    int panelBits = 1;
+    while ((1ull << panelBits) < (uint64_t)P) ++panelBits;
+    hipcub::DoubleBuffer<uint64_t> kb(dKeys, dKeysAlt);
+    hipcub::DoubleBuffer<uint32_t> vb(dSlots, dSlotsAlt);
+    size_t sortBytes = 0, scanBytes = 0;
+    BSMR_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, kb, vb, (int)slots, 0, 32 + panelBits, s));
+    BSMR_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, dPanelBlocks, dFirstBlock, (int)P + 1, s));
+    uint8_t* dTemp = nullptr;
+    size_t tempBytes = std::max(sortBytes, scanBytes) + 256;
+    if (!dev.alloc(&dTemp, tempBytes, "hipMalloc(sort scratch)")) return BSMR_ERR_OOM;
+    size_t need = tempBytes;
+    BSMR_HIP(hipcub::DeviceRadixSort::SortPairs(dTemp, need, kb, vb, (int)slots, 0, 32 + panelBits, s));
+    const uint64_t* sKeys = kb.Current();
+    const uint32_t* sSlots = vb.Current();
+    hipLaunchKernelGGL(bsmr::packCheckSorted, dim3((uint32_t)((slots + 255) / 256)), dim3(256), 0, s, sKeys, slots, d->N, dFlags);
+    hipLaunchKernelGGL(bsmr::packPanelCols, dim3(P / 256 + 1), dim3(256), 0, s, sKeys, dOffsets, P, d->N, dPanelCols, dPanelBlocks);
+    need = tempBytes;
+    BSMR_HIP(hipcub::DeviceScan::ExclusiveSum(dTemp, need, dPanelBlocks, dFirstBlock, (int)P + 1, s));
+    BSMR_HIP(hipGetLastError());
+    std::vector<uint32_t> panelCols(P);
+    uint32_t numBlocks = 0, flags = 0;
+    BSMR_HIP(hipMemcpyAsync(panelCols.data(), dPanelCols, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipMemcpyAsync(&numBlocks, dFirstBlock + P, 4, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipMemcpyAsync(&flags, dFlags, 4, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipStreamSynchronize(s));
+    if (flags & 1u) return BSMR_ERR_BAD_PLAN;
+    if ((flags & 2u) || numBlocks == 0) return kPackOnHost;
+    r.unionColumns = 0;
+    for (const uint32_t c : panelCols) r.unionColumns += c;
+    r.numBlocks = numBlocks;
+
+    // blocks: columns, destinations in accumulator order, per-row ranges
+    uint32_t *dPanelOfBlock, *dAbs, *dRowLo, *dRowHi, *dIsFirst, *dCountAtFirst, *dLoAtFirst, *dHiAtFirst, *dItemBefore;
+    if (!dev.alloc(&dPanelOfBlock, numBlocks, "hipMalloc") || !dev.alloc(&dAbs, (size_t)numBlocks * 256, "hipMalloc") ||
+        !dev.alloc(&dRowLo, (size_t)numBlocks * 16, "hipMalloc") || !dev.alloc(&dRowHi, (size_t)numBlocks * 16, "hipMalloc") ||
+        !dev.alloc(&dIsFirst, numBlocks, "hipMalloc") || !dev.alloc(&dCountAtFirst, numBlocks, "hipMalloc") ||
+        !dev.alloc(&dLoAtFirst, (size_t)numBlocks * 16, "hipMalloc") || !dev.alloc(&dHiAtFirst, (size_t)numBlocks * 16, "hipMalloc") ||
+        !dev.alloc(&dItemBefore, numBlocks, "hipMalloc"))
+        return BSMR_ERR_OOM;
+    DenseFormat out;
+    uint64_t bytes = 0;
+    uint32_t* dMaskWords = nullptr;
+    struct Undo {   // on any early return nothing of the half-built format survives
+        DenseFormat& f;
+        uint32_t*& words;
+        bool armed = true;
+        ~Undo() {
+            if (!armed) return;
+            dropDense(f);
+            if (words) (void)hipFree(words);
+        }
+    } undo{out, dMaskWords};
+    if (!keep(out.groupRows, panelRows.size(), bytes) || !keep(out.blockCols, (size_t)numBlocks * 16, bytes) ||
+        !keep(out.blockMask, numBlocks, bytes) || !keep(out.tiles8, (size_t)numBlocks * 256, bytes))
+        return BSMR_ERR_OOM;
+    if (!hipOk(hipMalloc(reinterpret_cast<void**>(&dMaskWords), (size_t)numBlocks * 48), "hipMalloc(plan)")) return BSMR_ERR_OOM;
+    BSMR_HIP(hipMemcpyAsync(out.groupRows, panelRows.data(), panelRows.size() * 4, hipMemcpyHostToDevice, s));
+    BSMR_HIP(hipMemsetAsync(dIsFirst, 0, (size_t)numBlocks * 4, s));
+    hipLaunchKernelGGL(bsmr::packPanelOfBlock, dim3(P), dim3(256), 0, s, dFirstBlock, P, dPanelOfBlock);
+    hipLaunchKernelGGL(bsmr::packBlocks, dim3((numBlocks + 3) / 4), dim3(256), 0, s, sKeys, sSlots, dOffsets, dValues, dPanelCols,
+                       dFirstBlock, dPanelOfBlock, numBlocks, d->nnz, out.blockCols, dAbs, dRowLo, dRowHi, out.blockMask, dCounters,
+                       dFlags);
+    const uint32_t perItem = (uint32_t)std::max(1, opt.blocksPerItem);
+    hipLaunchKernelGGL(bsmr::packItems, dim3(P), dim3(64), 0, s, dFirstBlock, dRowLo, dRowHi, perItem, dIsFirst, dCountAtFirst,
+                       dLoAtFirst, dHiAtFirst, dFlags, dMaxItem);
+    need = 0;
+    BSMR_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, dIsFirst, dItemBefore, (int)numBlocks, s));
+    uint8_t* dTemp2 = dTemp;
+    if (need > tempBytes) {
+        if (!dev.alloc(&dTemp2, need + 256, "hipMalloc(scan scratch)")) return BSMR_ERR_OOM;
+    } else {
+        need = tempBytes;
+    }
+    BSMR_HIP(hipcub::DeviceScan::ExclusiveSum(dTemp2, need, dIsFirst, dItemBefore, (int)numBlocks, s));
+    BSMR_HIP(hipGetLastError());
+    uint32_t before = 0, last = 0;
+    unsigned long long counters[2] = {0, 0};
+    BSMR_HIP(hipMemcpyAsync(&before, dItemBefore + (numBlocks - 1), 4, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipMemcpyAsync(&last, dIsFirst + (numBlocks - 1), 4, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipMemcpyAsync(&flags, dFlags, 4, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipMemcpyAsync(&out.maxItemBlocks, dMaxItem, 4, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipMemcpyAsync(counters, dCounters, 16, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipStreamSynchronize(s));
+    if (flags & 1u) return BSMR_ERR_BAD_PLAN;
+    if (flags & 2u) return kPackOnHost;
+    const uint32_t numItems = before + last;
+    r.numDenseEntries = counters[0];
+    r.numTiles = counters[1];
+
+    // items: records, windows, destinations, launch order
+    bsmr::DenseItem* dItems0;
+    uint32_t *dItemLo, *dRowBase0, *dWinMask0, *dFirstCol, *dFirstColAlt, *dIndex, *dIndexAlt;
+    uint16_t* dWinLen0;
+    if (!dev.alloc(&dItems0, numItems, "hipMalloc") || !dev.alloc(&dItemLo, (size_t)numItems * 16, "hipMalloc") ||
+        !dev.alloc(&dRowBase0, (size_t)numItems * 16, "hipMalloc") || !dev.alloc(&dWinLen0, (size_t)numItems * 16, "hipMalloc") ||
+        !dev.alloc(&dWinMask0, (size_t)numItems * 128, "hipMalloc") || !dev.alloc(&dFirstCol, numItems, "hipMalloc") ||
+        !dev.alloc(&dFirstColAlt, numItems, "hipMalloc") || !dev.alloc(&dIndex, numItems, "hipMalloc") ||
+        !dev.alloc(&dIndexAlt, numItems, "hipMalloc"))
+        return BSMR_ERR_OOM;
+    if (!keep(out.items, numItems, bytes) || !keep(out.rowBase, (size_t)numItems * 16, bytes) ||
+        !keep(out.winLen, (size_t)numItems * 16, bytes) || !keep(out.winMask, (size_t)numItems * 128, bytes))
+        return BSMR_ERR_OOM;
+    BSMR_HIP(hipMemsetAsync(dWinMask0, 0, (size_t)numItems * 512, s));
+    hipLaunchKernelGGL(bsmr::packItemRows, dim3((numBlocks + 15) / 16), dim3(256), 0, s, dIsFirst, dItemBefore, dCountAtFirst,
+                       dLoAtFirst, dHiAtFirst, dPanelOfBlock, out.blockCols, numBlocks, dItems0, dItemLo, dRowBase0, dWinLen0, dFirstCol,
+                       dIndex);
+    hipLaunchKernelGGL(bsmr::packEncode, dim3((numBlocks + 3) / 4), dim3(256), 0, s, dAbs, dItemBefore, dIsFirst, dItemLo, numBlocks,
+                       out.tiles8, dWinMask0, dMaskWords, dFlags);
+    hipcub::DoubleBuffer<uint32_t> ck(dFirstCol, dFirstColAlt);
+    hipcub::DoubleBuffer<uint32_t> ci(dIndex, dIndexAlt);
+    need = 0;
+    BSMR_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, ck, ci, (int)numItems, 0, 32, s));
+    uint8_t* dTemp3 = dTemp;
+    if (need > tempBytes) {
+        if (!dev.alloc(&dTemp3, need + 256, "hipMalloc(sort scratch)")) return BSMR_ERR_OOM;
+    } else {
+        need = tempBytes;
+    }
+    BSMR_HIP(hipcub::DeviceRadixSort::SortPairs(dTemp3, need, ck, ci, (int)numItems, 0, 32, s));
+    hipLaunchKernelGGL(bsmr::packPermute, dim3((numItems + 1) / 2), dim3(256), 0, s, ci.Current(), numItems, dItems0, dRowBase0,
+                       dWinLen0, dWinMask0, out.items, out.rowBase, out.winLen, out.winMask);
+    BSMR_HIP(hipGetLastError());
+    BSMR_HIP(hipMemcpyAsync(&flags, dFlags, 4, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipStreamSynchronize(s));
+    if (opt.maskTiles && !(flags & 4u)) {   // every tile row's offsets are consecutive: the 48-byte form
+        (void)hipFree(out.tiles8);
+        out.tiles8 = nullptr;
+        bytes -= (uint64_t)numBlocks * 256;
+        out.tilesM = reinterpret_cast<bsmr::TileMask*>(dMaskWords);
+        dMaskWords = nullptr;
+        bytes += (uint64_t)numBlocks * 48;
+    } else {
+        (void)hipFree(dMaskWords);
+        dMaskWords = nullptr;
+    }
+    out.H = 1;
+    out.numItems = numItems;
+    out.numBlocks = numBlocks;
+    out.numTiles = r.numTiles;
+    out.unionColumns = r.unionColumns;
+    undo.armed = false;
+    f = out;
+    indexBytes += bytes;
+    return BSMR_OK;
 }
 
 // Dense format for a call with inner dimension K.
@@ -1009,6 +1225,7 @@ int bsmr_plan_options_default(bsmr_plan_options* opt) {
     o.b_only_work_m = 100;
     o.overlap_streams = -1;
     o.mask_tiles = -1;
+    o.pack_on_device = -1;
     *opt = o;
     return BSMR_OK;
 }
@@ -1034,7 +1251,7 @@ int bsmr_plan_options_from_env(bsmr_plan_options* opt) {
         {"BSMR_SPARSE_LPE", &o.sparse_lpe}, {"BSMR_FREE_RESIDUE", &o.free_residue},
         {"BSMR_CONVERT_IN_KERNEL", &o.convert_in_kernel}, {"BSMR_CONVERT_SLICED", &o.convert_sliced}, {"BSMR_B_ONLY", &o.b_only},
         {"BSMR_B_ONLY_WORK_M", &o.b_only_work_m}, {"BSMR_OVERLAP_STREAMS", &o.overlap_streams},
-        {"BSMR_MASK_TILES", &o.mask_tiles},
+        {"BSMR_MASK_TILES", &o.mask_tiles}, {"BSMR_PACK_ON_DEVICE", &o.pack_on_device},
     };
     for (const auto& k : knobs) *k.field = envInt(k.name, *k.field);
     return BSMR_OK;
@@ -1180,13 +1397,47 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         const float rulesMs = msSince(tStart);
         const Clock::time_point tPack = Clock::now();
         bsmr::PackedPlan pk;
-        st = bsmr::packPlan(d, opt, pk);
-        if (st != BSMR_OK) return st;
+        // the default dense layout is built by kernels from the uploaded RPHM arrays when the dense part is large enough
+        // to repay the launches (csrc/pack_device.hpp); the residue and every other layout are packed on the host
+        DenseFormat deviceFormat;
+        uint64_t deviceFormatBytes = 0;
+        bool packedOnDevice = false;
+        if (opt.group == 1 && opt.columnOrder && opt.staged && !opt.forceWideTiles &&
+            (o.pack_on_device > 0 || (o.pack_on_device < 0 && d->block_offsets[P] >= 4096))) {
+            DevicePackResult r;
+            if ((st = bsmr::packRows(d, pk)) != BSMR_OK) return st;
+            st = packDenseOnDevice(d, opt, pk.panelRows, deviceFormat, deviceFormatBytes, r);
+            if (st == BSMR_OK) {
+                pk.H = 1;
+                pk.numGroups = P;
+                pk.staged = true;
+                pk.numDenseEntries = r.numDenseEntries;
+                pk.numBlocks = r.numBlocks;
+                pk.numTiles = r.numTiles;
+                pk.unionColumns = r.unionColumns;
+                if ((st = bsmr::packResidue(d, opt, pk)) != BSMR_OK) {
+                    dropDense(deviceFormat);
+                    return st;
+                }
+                packedOnDevice = true;
+            } else if (st != kPackOnHost) {
+                return st;
+            }
+        }
+        if (!packedOnDevice) {
+            pk = bsmr::PackedPlan();
+            st = bsmr::packPlan(d, opt, pk);
+            if (st != BSMR_OK) return st;
+        }
         const float packMs = msSince(tPack);
 
         bsmr_plan* p = new (std::nothrow) bsmr_plan;
-        if (!p) return BSMR_ERR_OOM;
+        if (!p) {
+            dropDense(deviceFormat);
+            return BSMR_ERR_OOM;
+        }
         p->device = device;
+        p->packedOnDevice = packedOnDevice;
         p->M = d->M;
         p->N = d->N;
         p->nnz = d->nnz;
@@ -1231,7 +1482,13 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
                           o.b_only != 0;
 
         const Clock::time_point tUpload = Clock::now();
-        st = uploadDense(p->fmt[0], pk, p->indexBytes);
+        if (packedOnDevice) {
+            p->fmt[0] = deviceFormat;
+            p->indexBytes += deviceFormatBytes;
+            st = BSMR_OK;
+        } else {
+            st = uploadDense(p->fmt[0], pk, p->indexBytes);
+        }
         p->fmt[0].stageInLds = outputMode == 2;
         p->fmt[0].streamWaves = streamWaves == 1 && p->fmt[0].maxItemBlocks <= 8 ? 1 : 4;
         if (st == BSMR_OK) st = upload(p->panelRows, pk.panelRows, p->indexBytes);
@@ -1291,6 +1548,43 @@ int bsmr_plan_destroy(bsmr_plan* plan) {
     if (hipSetDevice(plan->device) != hipSuccess) (void)hipGetLastError();
     freePlanDevice(plan);
     delete plan;
+    return BSMR_OK;
+}
+
+int bsmr_plan_format_digest(const bsmr_plan* p, uint64_t out[13]) {
+    if (!p || !out) return BSMR_ERR_INVALID_ARG;
+    BSMR_HIP(hipSetDevice(p->device));
+    const DenseFormat& f = p->fmt[0];
+    const uint64_t R = 16ull * (f.H ? f.H : 1), tiles = f.numBlocks * (f.H ? f.H : 1);
+    struct Part {
+        const void* ptr;
+        uint64_t bytes;
+    } parts[8] = {
+        {f.groupRows, f.groupRows ? (uint64_t)((p->numPanels + (f.H ? f.H : 1) - 1) / (f.H ? f.H : 1)) * R * 4 : 0},
+        {f.rowBase, f.rowBase ? (f.tiles8 || f.tilesM ? (uint64_t)f.numItems : (uint64_t)((p->numPanels + (f.H ? f.H : 1) - 1) / (f.H ? f.H : 1))) * R * 4 : 0},
+        {f.winLen, f.winLen ? (uint64_t)f.numItems * R * 2 : 0},
+        {f.winMask, f.winMask ? (uint64_t)f.numItems * R * (bsmr::kWindow / 32) * 4 : 0},
+        {f.blockCols, f.numBlocks * 64},
+        {f.tiles8 ? (const void*)f.tiles8 : f.tilesM ? (const void*)f.tilesM : f.tiles16 ? (const void*)f.tiles16 : (const void*)f.tiles32,
+         f.tiles8 ? tiles * 256 : f.tilesM ? tiles * 48 : f.tiles16 ? tiles * 512 : f.tiles32 ? tiles * 1024 : 0},
+        {f.blockMask, f.numBlocks},
+        {f.items, (uint64_t)f.numItems * sizeof(DenseItem)},
+    };
+    std::vector<uint8_t> host;
+    for (int i = 0; i < 8; ++i) {
+        uint64_t h = 0xcbf29ce484222325ull;
+        if (parts[i].ptr && parts[i].bytes) {
+            host.resize(parts[i].bytes);
+            BSMR_HIP(hipMemcpy(host.data(), parts[i].ptr, parts[i].bytes, hipMemcpyDeviceToHost));
+            for (const uint8_t b : host) h = (h ^ b) * 0x100000001b3ull;
+        }
+        out[i] = h;
+    }
+    out[8] = f.numItems;
+    out[9] = f.numBlocks;
+    out[10] = f.numTiles;
+    out[11] = f.unionColumns;
+    out[12] = f.tilesM ? 1 : 0;
     return BSMR_OK;
 }
 
@@ -1551,20 +1845,6 @@ uint32_t liveWarpMask(uint32_t T) {
     return members[0];
 }
 
-struct DeviceBuffers {
-    std::vector<void*> ptrs;
-    ~DeviceBuffers() {
-        for (void* p : ptrs) (void)hipFree(p);
-    }
-    template <typename T>
-    bool alloc(T** out, size_t count, const char* what) {
-        void* p = nullptr;
-        if (!hipOk(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)), what)) return false;
-        ptrs.push_back(p);
-        *out = static_cast<T*>(p);
-        return true;
-    }
-};
 
 }  // namespace
 

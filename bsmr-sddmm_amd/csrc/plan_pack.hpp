@@ -220,6 +220,20 @@ inline uint64_t countUnionColumns(const bsmr_rphm_desc* d, uint32_t h) {
     return total;
 }
 
+inline int packResidue(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan& out);
+
+// panelRows: the reordered rows, padded to whole panels
+inline int packRows(const bsmr_rphm_desc* d, PackedPlan& out) {
+    const uint32_t P = d->num_row_panels;
+    out.panelRows.assign((size_t)P * 16, 0);
+    for (size_t i = 0; i < out.panelRows.size(); ++i) {
+        const uint32_t row = i < d->num_nonzero_rows ? d->reordered_rows[i] : d->reordered_rows[0];
+        if (row >= d->M) return BSMR_ERR_BAD_PLAN;
+        out.panelRows[i] = row;
+    }
+    return BSMR_OK;
+}
+
 // Returns a bsmr_hip.h status.
 inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan& out) {
     // BSMR_PACK_TIMING=1: phase times on stderr
@@ -233,7 +247,6 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
     };
     const uint32_t P = d->num_row_panels;
     const uint64_t numRefBlocks = d->block_offsets[P];
-    const uint64_t numSparse = d->sparse_value_offsets[P];
     constexpr uint32_t kNone = 0xFFFFFFFFu;
 
     for (uint32_t p = 0; p < P; ++p)
@@ -242,12 +255,7 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
             return BSMR_ERR_BAD_PLAN;
 
     // ---- rows -------------------------------------------------------------
-    out.panelRows.assign((size_t)P * 16, 0);
-    for (size_t i = 0; i < out.panelRows.size(); ++i) {
-        const uint32_t row = i < d->num_nonzero_rows ? d->reordered_rows[i] : d->reordered_rows[0];
-        if (row >= d->M) return BSMR_ERR_BAD_PLAN;
-        out.panelRows[i] = row;
-    }
+    if (const int st = packRows(d, out)) return st;
 
     // first dense entry of every panel row (base of the DIRECT offsets)
     std::vector<uint32_t> panelRowBase((size_t)P * 16, 0);
@@ -538,6 +546,15 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
     }
 
     phase("item order");
+    const int st = packResidue(d, opt, out);
+    phase("residue entries");
+    return st;
+}
+
+// The sparse residue of the plan (out.panelRows and out.numDenseEntries are set): entries, work items, launch order.
+inline int packResidue(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan& out) {
+    const uint32_t P = d->num_row_panels;
+    const uint64_t numSparse = d->sparse_value_offsets[P];
     // ---- sparse residue -------------------------------------------------------
     // Entries are independent, so inside a panel they may be visited in any order:
     // with columnOrder they are sorted by column id and the work items by their first
@@ -565,7 +582,6 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
         }
     });
     out.numSparseEntries = numSparse;
-    phase("residue entries");
     if (out.numDenseEntries + numSparse != d->nnz) return BSMR_ERR_BAD_PLAN;
 
     const uint32_t perWG = (uint32_t)std::max(32, opt.sparsePerItem);

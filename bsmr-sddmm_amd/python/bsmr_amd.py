@@ -66,7 +66,7 @@ class PlanOptions(C.Structure):
         "promote_head", "dense_group", "dense_blocks_per_item", "stream_waves", "output_mode", "force_tile32",
         "column_order", "dense_stream", "dense_batch", "tile_group", "tile_blocks_per_item", "tile_depth",
         "sparse_entries_per_item", "sparse_lowp", "sparse_lpe", "free_residue", "convert_in_kernel", "convert_sliced",
-        "b_only", "b_only_work_m", "overlap_streams", "mask_tiles")]
+        "b_only", "b_only_work_m", "overlap_streams", "mask_tiles", "pack_on_device")]
 
 
 ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED = 0, 1, 2
@@ -119,6 +119,7 @@ HIP_SYMBOLS = {
     "bsmr_plan_destroy": (C.c_int, [C.c_void_p]),
     "bsmr_plan_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
     "bsmr_plan_build_times": (C.c_int, [C.c_void_p, C.POINTER(PlanBuildMs)]),
+    "bsmr_plan_format_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "bsmr_cluster_rows": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float,
                                     C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p]),
     "bsmr_sddmm_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,

@@ -177,6 +177,11 @@ typedef struct bsmr_plan_options {
     int32_t  mask_tiles;            /* destination tiles as 16-bit column masks + first offsets (48 instead of 256 bytes
                                        per tile; needs consecutive entries per tile row): 1 = whenever possible, 0 = never,
                                        -1 = when the 8-bit tiles would exceed the 32 MiB of L2 (default)     [MASK_TILES] */
+    /* plan build */
+    int32_t  pack_on_device;        /* the dense part's device format built by kernels from the uploaded RPHM arrays
+                                       (csrc/pack_device.hpp; byte-identical to the host packer, which still does every
+                                       layout but the default one): 1 = whenever possible, 0 = never,
+                                       -1 = from 4096 dense blocks (default)                               [PACK_ON_DEVICE] */
 } bsmr_plan_options;
 int bsmr_plan_options_default(bsmr_plan_options *opt);
 /* defaults, then every BSMR_<NAME> variable that is set */
@@ -197,6 +202,12 @@ typedef struct bsmr_plan_build_ms {
     float rules_ms, pack_ms, upload_ms, second_format_ms, total_ms;
 } bsmr_plan_build_ms;
 int bsmr_plan_build_times(const bsmr_plan *plan, bsmr_plan_build_ms *out);
+
+/* Fingerprint of the plan's first dense format as it lies in device memory: FNV-1a of groupRows, rowBase, winLen,
+ * winMask, blockCols, the destination tiles (8-bit or mask form), blockMask and the work items, then the numbers of
+ * items / blocks / tiles / union columns and 1 if the tiles are in the mask form (out[0..12]).  Two plans with equal
+ * fingerprints launch identical dense work; used to check the device packer against the host packer. */
+int bsmr_plan_format_digest(const bsmr_plan *plan, uint64_t out[13]);
 /* Which dense format a call with inner dimension K uses (any out pointer may be NULL):
  * panels per group, MFMA tiles executed, B columns gathered. */
 int bsmr_plan_dense_choice(const bsmr_plan *plan, uint32_t K, uint32_t *group_size,

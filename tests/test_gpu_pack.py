@@ -1,0 +1,114 @@
+"""The device packer (csrc/pack_device.hpp) against the host packer (csrc/plan_pack.hpp): the dense
+format it leaves in device memory must be the host packer's, array for array and byte for byte
+(bsmr_plan_format_digest), and SDDMM through it must match the CPU oracle.  Inputs it does not do (a block wider than a
+window, unsorted CSR rows) must fall back to the host packer and give the same plan."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import synth  # noqa: E402
+
+pytestmark = [pytest.mark.gpu, pytest.mark.shipping_rules]
+
+PARTS = ("groupRows", "rowBase", "winLen", "winMask", "blockCols", "tiles", "blockMask", "items",
+         "numItems", "numBlocks", "numTiles", "unionColumns", "maskForm")
+
+
+def _digest(engine, plan):
+    out = (C.c_uint64 * 13)()
+    assert engine.hip().bsmr_plan_format_digest(plan, out) == engine.OK
+    return dict(zip(PARTS, (int(v) for v in out)))
+
+
+def _both(engine, rows, cols, ro, ci, alpha, delta, **options):
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    pipe = engine.Pipeline(csr, alpha=alpha, delta=delta, device=-1)
+    arrays = pipe.arrays()
+    plans = {}
+    for where, flag in (("host", 0), ("device", 1)):
+        st, plan = engine.plan_from_arrays(rows, cols, csr.nnz, arrays, device=0,
+                                           options=engine.plan_options(pack_on_device=flag, **options))
+        assert st == engine.OK, where
+        plans[where] = plan
+    return csr, plans
+
+
+CASES = {
+    "nips_small": (lambda: synth.nips_like(rows=320, cols=1500, nnz=40000, seed=1), 0.3, 0.0, {}),
+    "nips_full": (lambda: synth.nips_like(), 0.3, 0.0, {}),
+    "nips_full_mask_tiles": (lambda: synth.nips_like(), 0.3, 0.0, {"mask_tiles": 1}),
+    "nips_hybrid_unpromoted": (lambda: synth.nips_like(), 0.3, 0.3, {"promote_average": 0, "fold_dense_below": 0}),
+    "nips_three_blocks_per_item": (lambda: synth.nips_like(), 0.3, 0.0, {"dense_blocks_per_item": 3}),
+    "mycielskian13_promoted": (lambda: synth.mycielskian_pattern(k=13), 0.3, 0.3, {}),
+    "bernoulli_2048": (lambda: synth.bernoulli(rows=2048, cols=2048, density=0.1, seed=4), 0.3, 0.0, {}),
+    "community_graph": (lambda: synth.community_graph(n=4096, avg_degree=64, communities=8, seed=3), 0.3, 0.1,
+                        {"fold_dense_below": 0}),
+    "fem_blocks": (lambda: synth.fem_node_blocks_like(n=20000, nnz=230000, seed=2), 0.3, 0.3, {"fold_dense_below": 0}),
+    "ragged_last_panel": (lambda: synth.random_pattern(1000 + 7, 900, 60000, seed=5, empty_rows=11), 0.3, 0.0, {}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_packer_equals_host_packer(engine, oracle, name):
+    make, alpha, delta, options = CASES[name]
+    rows, cols, ro, ci = make()
+    csr, plans = _both(engine, rows, cols, ro, ci, alpha, delta, **options)
+    try:
+        host, device = _digest(engine, plans["host"]), _digest(engine, plans["device"])
+        assert host["numBlocks"] > 0, "the case must have a dense part"
+        assert device == host
+        a, b = engine.PlanStats(), engine.PlanStats()     # plan statistics follow
+        assert engine.hip().bsmr_plan_get_stats(plans["host"], a) == engine.OK
+        assert engine.hip().bsmr_plan_get_stats(plans["device"], b) == engine.OK
+        for field, _ in engine.PlanStats._fields_:
+            assert getattr(a, field) == getattr(b, field), field
+        # and the plan computes: SDDMM through the device-packed plan against the oracle
+        K = 64
+        A, B = engine.make_data(rows * K, 5489), engine.make_data(cols * K, 5490)
+        dev = torch.device("cuda:0")
+        tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+        tP = torch.full((csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+        engine.sddmm(plans["device"], K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
+        torch.cuda.synchronize()
+        bad, first = oracle.check_data(oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B), tP.cpu().numpy())
+        assert bad == 0, (bad, first)
+    finally:
+        for plan in plans.values():
+            engine.plan_destroy(plan)
+
+
+def test_inputs_left_to_the_host_packer(engine):
+    """CSR rows with unsorted columns make a block span more than a window: the device packer hands the plan over to
+    the host packer (direct 16-bit offsets) and the result is the same plan."""
+    rng = np.random.default_rng(3)
+    rows, cols = 64, 6000
+    per_row = [rng.permutation(cols)[:3000] for _ in range(rows)]          # unsorted columns
+    ro = np.zeros(rows + 1, dtype=np.uint32)
+    ro[1:] = np.cumsum([len(c) for c in per_row])
+    ci = np.concatenate(per_row).astype(np.uint32)
+    csr, plans = _both(engine, rows, cols, ro, ci, 0.3, 0.0)
+    try:
+        host, device = _digest(engine, plans["host"]), _digest(engine, plans["device"])
+        assert host["numBlocks"] > 0 and host["winLen"] == device["winLen"]
+        assert device == host
+    finally:
+        for plan in plans.values():
+            engine.plan_destroy(plan)
+
+
+def test_build_times_say_where_the_format_was_packed(engine):
+    rows, cols, ro, ci = synth.nips_like()
+    csr, plans = _both(engine, rows, cols, ro, ci, 0.3, 0.0)
+    try:
+        times = {}
+        for where, plan in plans.items():
+            t = engine.PlanBuildMs()
+            assert engine.hip().bsmr_plan_build_times(plan, t) == engine.OK
+            times[where] = t.pack_ms
+            assert t.total_ms >= t.pack_ms > 0
+        print(f"nips-like 21 656 blocks: pack on host {times['host']:.1f} ms, on device {times['device']:.1f} ms")
+    finally:
+        for plan in plans.values():
+            engine.plan_destroy(plan)
