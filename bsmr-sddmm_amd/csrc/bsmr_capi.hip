@@ -1420,7 +1420,7 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
                     return st;
                 }
                 packedOnDevice = true;
-            } else if (st != kPackOnHost) {
+            } else if (st != kPackOnHost && st != BSMR_ERR_OOM) {   // (no room for the scratch arrays: the host packer needs none)
                 return st;
             }
         }
