@@ -15,10 +15,16 @@ REPO = Path(__file__).resolve().parent.parent
 rnd, tag, workload, mode = sys.argv[1:5]
 src = REPO / "gpurun_out" / f"prof_{tag}"
 dst = REPO / "profiles"
-stats = glob.glob(str(src / "stats" / "**" / "*kernel_stats.csv"), recursive=True)[0]
+def newest(pattern):
+    """gpurun merges a call's files into gpurun_out/ without removing those of earlier calls: one file per pass, the latest."""
+    files = glob.glob(pattern, recursive=True)
+    return max(files, key=lambda f: Path(f).stat().st_mtime) if files else None
+
+
+stats = newest(str(src / "stats" / "**" / "*kernel_stats.csv"))
 (dst / f"{rnd}_{tag}_kernel_stats.csv").write_text(Path(stats).read_text())
 pmc = collections.defaultdict(dict)
-for f in glob.glob(str(src / "pmc_*" / "**" / "*counter_collection.csv"), recursive=True):
+for f in filter(None, (newest(str(d / "**" / "*counter_collection.csv")) for d in sorted(src.glob("pmc_*")) if d.is_dir())):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "bsmr::" in r["Kernel_Name"]:
