@@ -47,7 +47,15 @@ CASES = {
                         {"fold_dense_below": 0}),
     "fem_blocks": (lambda: synth.fem_node_blocks_like(n=20000, nnz=230000, seed=2), 0.3, 0.3, {"fold_dense_below": 0}),
     "ragged_last_panel": (lambda: synth.random_pattern(1000 + 7, 900, 60000, seed=5, empty_rows=11), 0.3, 0.0, {}),
+    "fem_blocks_full_size": (lambda: synth.fem_node_blocks_like(), 0.3, 0.3, {}),          # 7 575 panels, BASELINE configs[2] size
+    "one_panel": (lambda: synth.random_pattern(16, 3000, 9000, seed=6), 0.3, 0.0, {"fold_dense_below": 0}),
+    "two_blocks_per_item": (lambda: synth.bernoulli(rows=512, cols=8192, density=0.05, seed=8), 0.5, 0.0, {"dense_blocks_per_item": 2}),
 }
+for _seed, (_rows, _cols, _nnz, _delta) in enumerate(((333, 777, 30000, 0.0), (2000, 300, 90000, 0.2), (4111, 4111, 200000, 0.1),
+                                                     (97, 20000, 150000, 0.05), (6000, 64, 100000, 0.0))):
+    CASES[f"random_{_rows}x{_cols}_delta{_delta}"] = (
+        lambda r=_rows, c=_cols, n=_nnz, sd=_seed: synth.random_pattern(r, c, n, seed=20 + sd, empty_rows=r // 50),
+        0.3, _delta, {"promote_average": 0, "fold_dense_below": 0})
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
