@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -118,6 +119,12 @@ struct bsmr_plan {
     TileFormatDev tiles[5];
     bool useTiles = false;         // options.dense_engine: BSMR_ENGINE_TILES / _SHARED
     bool sharedB = false;          // ... _SHARED: B images shared by the four waves of a workgroup (denseShared)
+    bool tunable = false;          // options.dense_engine == BSMR_ENGINE_TUNED: the two flags above are set per call ...
+    struct Tuned {
+        int engine = BSMR_ENGINE_STREAM, group = 0, blocksPerItem = 0;   // 0 = the engine's own rule
+    };
+    std::map<uint64_t, Tuned> tuned;   // ... from what bsmr_plan_tune measured for (K << 8 | mode); untuned calls stream
+    int tileGroupNow = 0, tileBlocksNow = 0;   // tuned group size / blocks per item of the call being prepared
     bsmr_plan_options opt{};       // what the plan was built with
 
     // hybrid plans: the residue kernel runs on a side stream beside the dense kernel (reference
@@ -570,7 +577,7 @@ inline uint32_t tilesMaxGroup(const bsmr_plan* p, uint32_t K) {
 // Panels per group for a call with inner dimension K.
 uint32_t chooseTileGroup(const bsmr_plan* p, uint32_t K) {
     const uint32_t maxH = tilesMaxGroup(p, K), minH = p->sharedB ? 4u : 1u;
-    const int forced = p->opt.tile_group;
+    const int forced = p->tileGroupNow > 0 ? p->tileGroupNow : p->opt.tile_group;
     if (forced > 0) {
         uint32_t h = minH;
         while (h * 2 <= (uint32_t)forced && h * 2 <= maxH) h *= 2;
@@ -605,7 +612,7 @@ int ensureTiles(bsmr_plan* p, uint32_t H) {
         uint32_t perItem = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(2 * H, c.blocks / 2048));
         if (p->sharedB)   // workgroups of four waves: two per CU and a few rounds; whole steps of four blocks
             perItem = (uint32_t)std::min<uint64_t>(bsmr::kTileMaxItemBlocks, std::max<uint64_t>(8, c.blocks / 1024 / 4 * 4));
-        const int forcedBlocks = p->opt.tile_blocks_per_item;
+        const int forcedBlocks = p->tileBlocksNow > 0 ? p->tileBlocksNow : p->opt.tile_blocks_per_item;
         if (forcedBlocks > 0) perItem = (uint32_t)std::min<int>(forcedBlocks, bsmr::kTileMaxItemBlocks);
         if (t.H && t.blocksPerItem == perItem) return BSMR_OK;
         if (t.H) {
@@ -1021,7 +1028,15 @@ inline bool needsWorkspace(const bsmr_plan* p, int mode, uint32_t K, uint32_t ba
 }
 
 // device format of the dense part for calls with inner dimension K (allocates on first use)
-int prepareDense(bsmr_plan* p, uint32_t K) {
+int prepareDense(bsmr_plan* p, uint32_t K, int mode) {
+    if (p->tunable) {
+        const auto it = p->tuned.find(((uint64_t)K << 8) | (uint32_t)mode);
+        const bsmr_plan::Tuned choice = it == p->tuned.end() ? bsmr_plan::Tuned{} : it->second;
+        p->useTiles = choice.engine != BSMR_ENGINE_STREAM;
+        p->sharedB = choice.engine == BSMR_ENGINE_SHARED;
+        p->tileGroupNow = choice.group;
+        p->tileBlocksNow = choice.blocksPerItem;
+    }
     if (!tilesEngine(p, K)) return BSMR_OK;
     return ensureTiles(p, chooseTileGroup(p, K));
 }
@@ -1237,7 +1252,7 @@ int bsmr_plan_options_from_env(bsmr_plan_options* opt) {
     bsmr_plan_options& o = *opt;
     if (const char* e = std::getenv("BSMR_DENSE_ENGINE")) {
         const std::string v(e);
-        o.dense_engine = v == "tiles" ? BSMR_ENGINE_TILES : v == "shared" ? BSMR_ENGINE_SHARED : BSMR_ENGINE_STREAM;
+        o.dense_engine = v == "tiles" ? BSMR_ENGINE_TILES : v == "shared" ? BSMR_ENGINE_SHARED : v == "tuned" ? BSMR_ENGINE_TUNED : BSMR_ENGINE_STREAM;
     }
     struct { const char* name; int32_t* field; } knobs[] = {
         {"BSMR_FOLD_DENSE_BELOW", &o.fold_dense_below}, {"BSMR_PROMOTE_AVERAGE", &o.promote_average},
@@ -1275,7 +1290,7 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         o.struct_size = (uint32_t)sizeof(bsmr_plan_options);
     }
     if (o.sparse_lpe != 4 && o.sparse_lpe != 8 && o.sparse_lpe != 16) o.sparse_lpe = 0;
-    if (o.dense_engine < BSMR_ENGINE_STREAM || o.dense_engine > BSMR_ENGINE_SHARED) return BSMR_ERR_INVALID_ARG;
+    if (o.dense_engine < BSMR_ENGINE_STREAM || o.dense_engine > BSMR_ENGINE_TUNED) return BSMR_ERR_INVALID_ARG;
     if (!d->block_offsets || !d->sparse_value_offsets || (!d->reordered_rows && d->num_nonzero_rows))
         return BSMR_ERR_INVALID_ARG;
     const uint32_t P = d->num_row_panels;
@@ -1455,7 +1470,8 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         {
             p->useTiles = o.dense_engine == BSMR_ENGINE_TILES || o.dense_engine == BSMR_ENGINE_SHARED;
             p->sharedB = o.dense_engine == BSMR_ENGINE_SHARED;
-            if (p->useTiles && pk.numBlocks) {
+            p->tunable = o.dense_engine == BSMR_ENGINE_TUNED;
+            if ((p->useTiles || p->tunable) && pk.numBlocks) {
                 st = bsmr::collectDense(d, p->hostDense);
                 if (st != BSMR_OK) {
                     delete p;
@@ -1666,7 +1682,7 @@ int bsmr_plan_reserve(bsmr_plan* plan, uint32_t K) {
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     BSMR_HIP(hipSetDevice(plan->device));
-    if (int st = prepareDense(plan, K)) return st;
+    if (int st = prepareDense(plan, K, BSMR_COMPUTE_F16)) return st;
     if (!plan->convertPass && !convertsBOnly(plan, K)) return BSMR_OK;
     return reserve(plan, K);
 }
@@ -1676,7 +1692,7 @@ int bsmr_sddmm(bsmr_plan* plan, uint32_t K, const float* A, const float* B, floa
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     BSMR_HIP(hipSetDevice(plan->device));
-    if (mode != BSMR_COMPUTE_F32 && (st = prepareDense(plan, K)) != BSMR_OK) return st;
+    if (mode != BSMR_COMPUTE_F32 && (st = prepareDense(plan, K, mode)) != BSMR_OK) return st;
     if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;
     return runPieces(plan, K, A, B, P, mode, static_cast<hipStream_t>(stream), 7);
 }
@@ -1689,7 +1705,7 @@ int bsmr_sddmm_batch(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     if (num_batches > 65535u || (uint64_t)K * num_batches > 0xFFFFFFFFull) return BSMR_ERR_INVALID_ARG;
     BSMR_HIP(hipSetDevice(plan->device));
     const Queue s(static_cast<hipStream_t>(stream), bsmr::Batch{(uint64_t)plan->M * K, (uint64_t)plan->N * K, plan->nnz, num_batches});
-    if (mode != BSMR_COMPUTE_F32 && (st = prepareDense(plan, K)) != BSMR_OK) return st;
+    if (mode != BSMR_COMPUTE_F32 && (st = prepareDense(plan, K, mode)) != BSMR_OK) return st;
     if (needsWorkspace(plan, mode, K, num_batches)) {
         // the batches are contiguous, so one conversion pass covers all of them
         if ((st = reserve(plan, K * num_batches)) != BSMR_OK) return st;
@@ -1734,7 +1750,7 @@ int bsmr_sddmm_lowp(bsmr_plan* plan, uint32_t K, const void* A16, const void* B1
     if (plan->numSparseItems && !residueLowp && (!A || !B)) return BSMR_ERR_INVALID_ARG;  // fp32 residue
     BSMR_HIP(hipSetDevice(plan->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (int pst = prepareDense(plan, K)) return pst;
+    if (int pst = prepareDense(plan, K, mode)) return pst;
     int st = mode == BSMR_COMPUTE_F16
                  ? launchDense16<0>(plan, K, static_cast<const uint16_t*>(A16),
                                     static_cast<const uint16_t*>(B16), P, s)
@@ -1754,7 +1770,7 @@ int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     if (st != BSMR_OK) return st;
     if (!out || iters <= 0 || warmup < 0) return BSMR_ERR_INVALID_ARG;
     BSMR_HIP(hipSetDevice(plan->device));
-    if (mode != BSMR_COMPUTE_F32 && (st = prepareDense(plan, K)) != BSMR_OK) return st;
+    if (mode != BSMR_COMPUTE_F32 && (st = prepareDense(plan, K, mode)) != BSMR_OK) return st;
     if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1784,6 +1800,74 @@ int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (st == BSMR_OK) *out = t;
+    return st;
+}
+
+int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode, void* stream,
+                   bsmr_tune_report* report) {
+    int st = checkCall(plan, K, A, B, P, mode);
+    if (st != BSMR_OK) return st;
+    if (!plan->tunable) return BSMR_ERR_INVALID_ARG;
+    bsmr_tune_report r{BSMR_ENGINE_STREAM, -1.f, -1.f, -1.f, 0, 0};
+    BSMR_HIP(hipSetDevice(plan->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t key = ((uint64_t)K << 8) | (uint32_t)mode;
+    bsmr_plan::Tuned best;
+    if (mode != BSMR_COMPUTE_F32 && plan->hostDense.entries() != 0 && tilesServeK(K) && !plan->convertInKernel) {
+        if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        BSMR_HIP(hipEventCreate(&e0));
+        if (!hipOk(hipEventCreate(&e1), "hipEventCreate")) {
+            (void)hipEventDestroy(e0);
+            return BSMR_ERR_HIP;
+        }
+        // the candidates: the streaming engine, the tiles engine with its own rules, and the shared-B engine over the
+        // group sizes and work-item lengths it serves at this K (its own rule first)
+        std::vector<bsmr_plan::Tuned> candidates = {{BSMR_ENGINE_STREAM, 0, 0}, {BSMR_ENGINE_TILES, 0, 0}, {BSMR_ENGINE_SHARED, 0, 0}};
+        const uint32_t sharedMaxH = std::min<uint32_t>(16u, 4u * (32u / (K / 32u)));
+        for (int h = 4; h <= (int)std::min<uint32_t>(8u, sharedMaxH); h *= 2)
+            for (const int blocks : {8, 16, 32}) candidates.push_back({BSMR_ENGINE_SHARED, h, blocks});
+        float bestUs = -1.f;
+        st = runPieces(plan, K, A, B, P, mode, s, 1);   // the converted operands every candidate reads
+        for (size_t c = 0; c < candidates.size() && st == BSMR_OK; ++c) {
+            plan->tuned[key] = candidates[c];
+            if (const int pst = prepareDense(plan, K, mode)) {
+                if (candidates[c].engine == BSMR_ENGINE_STREAM) st = pst;   // (an engine whose format cannot be built does not compete)
+                continue;
+            }
+            for (int i = 0; i < 3 && st == BSMR_OK; ++i) st = runPieces(plan, K, A, B, P, mode, s, 2);
+            hipError_t e = hipEventRecord(e0, s);
+            for (int i = 0; i < 10 && st == BSMR_OK; ++i) st = runPieces(plan, K, A, B, P, mode, s, 2);
+            if (e == hipSuccess) e = hipEventRecord(e1, s);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (!hipOk(e, "event timing")) st = BSMR_ERR_HIP;
+            const float us = ms * 100.f;   // 10 launches, microseconds each
+            float& slot = candidates[c].engine == BSMR_ENGINE_STREAM ? r.stream_us : candidates[c].engine == BSMR_ENGINE_TILES ? r.tiles_us : r.shared_us;
+            const bool engineBest = slot < 0.f || us < slot;
+            if (engineBest) slot = us;
+            if (bestUs < 0.f || us < bestUs) {
+                bestUs = us;
+                best = candidates[c];
+            }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (st != BSMR_OK) {
+            plan->tuned.erase(key);
+            return st;
+        }
+    }
+    plan->tuned[key] = best;
+    r.chosen_engine = best.engine;
+    r.chosen_group = best.group;
+    r.chosen_blocks_per_item = best.blocksPerItem;
+    // leave a complete result in P and the chosen engine's format in place
+    if ((st = prepareDense(plan, K, mode)) != BSMR_OK) return st;
+    if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;
+    st = runPieces(plan, K, A, B, P, mode, s, 7);
+    if (st == BSMR_OK && report) *report = r;
     return st;
 }
 

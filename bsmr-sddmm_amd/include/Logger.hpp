@@ -90,6 +90,7 @@ struct Logger {
     float reorderingTime_ = 0.0f;
     // MI355X additions (printed after the reference's keys)
     std::string computeMode_ = "f16";
+    std::string denseEngine_ = "stream";   // dense engine of the timed calls (bsmr_plan_tune, BSMR_DENSE_ENGINE=tuned)
     float convertTime_ = 0.0f;
     float denseTime_ = 0.0f;
     float sparseTime_ = 0.0f;
@@ -148,6 +149,7 @@ void Logger::printLogInformation(std::ostream& out) const {
     out << "[mi355x_convert_us : " << convertTime_ * 1e3f << "]\n";
     out << "[mi355x_dense_us : " << denseTime_ * 1e3f << "]\n";
     out << "[mi355x_sparse_us : " << sparseTime_ * 1e3f << "]\n";
+    out << "[mi355x_dense_engine : " << denseEngine_ << "]\n";
     out << std::setprecision(2);
     if (errorRate_ > 0)
         out << "[checkResults : NO PASS Error rate : " << std::fixed << std::setprecision(2)

@@ -43,6 +43,11 @@ class RphmDesc(C.Structure):
                 ("sparse_relative_rows", u32p), ("sparse_col_indices", u32p)]
 
 
+class TuneReport(C.Structure):
+    _fields_ = [("chosen_engine", C.c_int32), ("stream_us", C.c_float), ("tiles_us", C.c_float), ("shared_us", C.c_float),
+                ("chosen_group", C.c_int32), ("chosen_blocks_per_item", C.c_int32)]
+
+
 class PlanBuildMs(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("rules_ms", "pack_ms", "upload_ms", "second_format_ms", "total_ms")]
 
@@ -69,7 +74,8 @@ class PlanOptions(C.Structure):
         "b_only", "b_only_work_m", "overlap_streams", "mask_tiles", "pack_on_device")]
 
 
-ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED = 0, 1, 2
+ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED, ENGINE_TUNED = 0, 1, 2, 3
+ENGINE_NAMES = {0: "stream", 1: "tiles", 2: "shared"}
 
 
 class ReorderingReport(C.Structure):
@@ -120,6 +126,8 @@ HIP_SYMBOLS = {
     "bsmr_plan_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
     "bsmr_plan_build_times": (C.c_int, [C.c_void_p, C.POINTER(PlanBuildMs)]),
     "bsmr_plan_format_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "bsmr_plan_tune": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                C.POINTER(TuneReport)]),
     "bsmr_cluster_rows": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float,
                                     C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p]),
     "bsmr_sddmm_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
@@ -483,6 +491,15 @@ def sddmm_operator_sharded(csr: CSR, K: int, A, B, devices, alpha=0.3, delta=0.3
 # --- device entry points (pointers are integers, e.g. torch.Tensor.data_ptr()) ---
 def sddmm(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, mode=COMPUTE_F16, stream: int = 0):
     _check(hip().bsmr_sddmm(plan, K, A_ptr, B_ptr, P_ptr, mode, stream), "bsmr_sddmm")
+
+
+def plan_tune(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, mode=COMPUTE_F16, stream: int = 0) -> dict:
+    """bsmr_plan_tune: time the dense engines for calls with this (K, mode) on these operands and keep the fastest
+    (the plan must have been created with dense_engine = ENGINE_TUNED).  P holds the result afterwards."""
+    r = TuneReport()
+    _check(hip().bsmr_plan_tune(plan, K, A_ptr, B_ptr, P_ptr, mode, stream, C.byref(r)), "bsmr_plan_tune")
+    return {"chosen": ENGINE_NAMES[r.chosen_engine], "stream_us": round(r.stream_us, 2), "tiles_us": round(r.tiles_us, 2),
+            "shared_us": round(r.shared_us, 2), "group": r.chosen_group, "blocks_per_item": r.chosen_blocks_per_item}
 
 
 def sddmm_batch(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, num_batches: int, mode=COMPUTE_F16, stream: int = 0):

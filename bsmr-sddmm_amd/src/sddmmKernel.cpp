@@ -3,6 +3,7 @@
 #include "sddmmKernel.hpp"
 
 #include <chrono>
+#include <string>
 
 #include <cstdio>
 
@@ -35,6 +36,13 @@ void sddmm_gpu(UIN M, UIN N, UIN K, const float* matrixA, const float* matrixB, 
                 bsmr_strerror(rphm.planStatus()));
         logger.status_ = rphm.planStatus() != BSMR_OK ? rphm.planStatus() : BSMR_ERR_INVALID_ARG;
         return;
+    }
+    // a tunable plan (BSMR_DENSE_ENGINE=tuned) first measures its dense engines on these operands; any other plan
+    // answers BSMR_ERR_INVALID_ARG and runs as it was built
+    bsmr_tune_report tuned{};
+    if (bsmr_plan_tune(rphm.plan(), K, matrixA, matrixB, matrixP, g_computeMode, nullptr, &tuned) == BSMR_OK) {
+        static const char* const names[] = {"stream", "tiles", "shared"};
+        logger.denseEngine_ = std::string(names[tuned.chosen_engine >= 0 && tuned.chosen_engine <= 2 ? tuned.chosen_engine : 0]) + " (tuned)";
     }
     bsmr_timing t{};
     const int iters = logger.numITER_ > 0 ? logger.numITER_ : 1;

@@ -138,6 +138,8 @@ int bsmr_device_synchronize(int device);
 #define BSMR_ENGINE_STREAM  0  /* dense part: per-panel streaming kernels (denseStream / denseGroups), the default */
 #define BSMR_ENGINE_TILES   1  /* dense part: "tiles" format, H panels per wave-private B image (denseTiles)     */
 #define BSMR_ENGINE_SHARED  2  /* dense part: "tiles" format, B images shared by the 4 waves of a workgroup        */
+#define BSMR_ENGINE_TUNED   3  /* the plan keeps what every engine needs; calls use the streaming engine until
+                                  bsmr_plan_tune has timed the three for their (K, mode) and then the fastest          */
 typedef struct bsmr_plan_options {
     uint32_t struct_size;           /* sizeof(bsmr_plan_options) of the caller                                        */
     int32_t  dense_engine;          /* BSMR_ENGINE_*                                                    [DENSE_ENGINE] */
@@ -202,6 +204,21 @@ typedef struct bsmr_plan_build_ms {
     float rules_ms, pack_ms, upload_ms, second_format_ms, total_ms;
 } bsmr_plan_build_ms;
 int bsmr_plan_build_times(const bsmr_plan *plan, bsmr_plan_build_ms *out);
+
+/* Which dense engine is fastest for calls with this K and mode is measured, not modelled: bsmr_plan_tune times the
+ * dense part of the plan under each engine on the caller's operands (HIP events on `stream`, a conversion pass first,
+ * 3 warm-up + 10 timed launches each) and the plan uses the fastest for every later call with the same (K, mode).
+ * Needs a plan created with dense_engine = BSMR_ENGINE_TUNED; P is overwritten with the (correct) result.  The
+ * reference has no counterpart: it tunes (alpha, delta) per matrix by sweeping (src/sddmm.cu:62-118). */
+typedef struct bsmr_tune_report {
+    int32_t chosen_engine;                    /* BSMR_ENGINE_STREAM / _TILES / _SHARED */
+    float   stream_us, tiles_us, shared_us;   /* best dense-kernel time per launch of each engine; < 0: not measured
+                                                 (the engine does not serve this call, or only one engine does) */
+    int32_t chosen_group;                     /* panels per group / blocks per work item of the winner where they were */
+    int32_t chosen_blocks_per_item;           /* part of the search (the shared-B engine), else 0 = the engine's own rule */
+} bsmr_tune_report;
+int bsmr_plan_tune(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev, float *P_dev, int mode, void *stream,
+                   bsmr_tune_report *report /* may be NULL */);
 
 /* Fingerprint of the plan's first dense format as it lies in device memory: FNV-1a of groupRows, rowBase, winLen,
  * winMask, blockCols, the destination tiles (8-bit or mask form), blockMask and the work items, then the numbers of
