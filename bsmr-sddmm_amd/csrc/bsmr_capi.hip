@@ -115,16 +115,21 @@ struct bsmr_plan {
 
     // "tiles" engine: the dense entries on the host, census per group size, device formats built on first use
     bsmr::HostDense hostDense;
-    bsmr::TileCensus census[5];    // H = 1, 2, 4, 8, 16
+    mutable bsmr::TileCensus census[5];    // H = 1, 2, 4, 8, 16: blocks / tiles / union columns, counted on first use
+    mutable bool censusDone[5] = {false, false, false, false, false};
     TileFormatDev tiles[5];
     bool useTiles = false;         // options.dense_engine: BSMR_ENGINE_TILES / _SHARED
     bool sharedB = false;          // ... _SHARED: B images shared by the four waves of a workgroup (denseShared)
     bool tunable = false;          // options.dense_engine == BSMR_ENGINE_TUNED: the two flags above are set per call ...
     struct Tuned {
         int engine = BSMR_ENGINE_STREAM, group = 0, blocksPerItem = 0;   // 0 = the engine's own rule
+        int format = -1;    // streaming engine: 0 = one panel per group, 1 = the grouped format, -1 = chooseFormat's rule
+        int bOnly = -1;     // all-sparse plans: 1 = convert B alone and read 16-bit operands, 0 = fp32 residue, -1 = the rule
+        int overlap = -1;   // hybrid plans: 1 = residue kernel on the side stream, 0 = one stream, -1 = as the plan was built
     };
     std::map<uint64_t, Tuned> tuned;   // ... from what bsmr_plan_tune measured for (K << 8 | mode); untuned calls stream
     int tileGroupNow = 0, tileBlocksNow = 0;   // tuned group size / blocks per item of the call being prepared
+    int formatNow = -1, bOnlyNow = -1, overlapNow = -1;   // ... and its format / conversion / stream choices
     bsmr_plan_options opt{};       // what the plan was built with
 
     // hybrid plans: the residue kernel runs on a side stream beside the dense kernel (reference
@@ -481,6 +486,7 @@ const DenseFormat& chooseFormat(const bsmr_plan* p, uint32_t K) {
     //   mycielskian15, residue promoted, 2.30x fewer columns: K=128 34.6 vs 41.0, K=256 62.1 vs 79.9, K=512 121 vs 119
     //   mycielskian14, 2.45x: K=256 27.2 vs 39.9, K=512 48.8 vs 58.4       nips-like, 1.94x: K=512 31.7 vs 34.3
     //   4096^2 Bernoulli(0.1), 3.26x: K=128 (218 MB) 17.9 vs 18.9, K=256 (437 MB) 32.5 vs 25.1, K=512 62.7 vs 36.9
+    if (p->formatNow == 0 || (p->formatNow == 1 && p->fmt[1].H)) return p->fmt[p->formatNow];   // measured (bsmr_plan_tune)
     if (p->fmt[1].H && p->fmt[0].unionColumns * (uint64_t)K * 2ull >= kGroupedGatherBytes &&
         p->fmt[0].unionColumns * 2 >= 5 * p->fmt[1].unionColumns)
         return p->fmt[1];
@@ -566,6 +572,14 @@ int launchGroupsH(const DenseFormat& f, const uint16_t* A16, const uint16_t* B16
 
 // ---- "tiles" engine (csrc/tile_format.hpp, csrc/tile_kernels.hpp) ---------------------------------------
 inline int tileSlot(uint32_t H) { return H == 1 ? 0 : H == 2 ? 1 : H == 4 ? 2 : H == 8 ? 3 : 4; }
+inline const bsmr::TileCensus& censusOf(const bsmr_plan* p, uint32_t H) {
+    const int slot = tileSlot(H);
+    if (!p->censusDone[slot]) {
+        p->census[slot] = bsmr::tileCensus(p->hostDense, H);
+        p->censusDone[slot] = true;
+    }
+    return p->census[slot];
+}
 
 // K for which denseTiles is instantiated, and the largest group whose A fragments fit the register budget
 // (H * K / 32 fragments of 4 VGPRs per lane; 32 fragments = 128 VGPRs)
@@ -588,7 +602,7 @@ uint32_t chooseTileGroup(const bsmr_plan* p, uint32_t K) {
     uint32_t best = minH;
     double bestCost = 0;
     for (uint32_t h = minH; h <= maxH; h *= 2) {
-        const bsmr::TileCensus& c = p->census[tileSlot(h)];
+        const bsmr::TileCensus& c = censusOf(p, h);
         if (c.blocks == 0) continue;
         const double items = std::max<double>(1024.0, (double)c.blocks / 16.0);
         const double bytes = (double)c.blocks * 32.0 * K + items * h * 32.0 * K;
@@ -607,7 +621,7 @@ uint32_t chooseTileGroup(const bsmr_plan* p, uint32_t K) {
 int ensureTiles(bsmr_plan* p, uint32_t H) {
     TileFormatDev& t = p->tiles[tileSlot(H)];
     try {
-        const bsmr::TileCensus& c = p->census[tileSlot(H)];
+        const bsmr::TileCensus& c = censusOf(p, H);
         // blocks per work item: enough items for two waves per SIMD, long enough to repay the A fragments
         uint32_t perItem = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(2 * H, c.blocks / 2048));
         if (p->sharedB)   // workgroups of four waves: two per CU and a few rounds; whole steps of four blocks
@@ -1016,6 +1030,7 @@ int checkCall(const bsmr_plan* p, uint32_t K, const void* A, const void* B, cons
 // after it): B alone is converted and the residue kernel rounds A's rows while it stages them in LDS
 inline bool convertsBOnly(const bsmr_plan* p, uint32_t K, uint32_t batches = 1) {
     if (!p->convertBOnly || (size_t)16 * (2u * K + bsmr::kSparseLdsPad16) > 64 * 1024) return false;
+    if (p->bOnlyNow >= 0) return p->bOnlyNow == 1;   // measured (bsmr_plan_tune)
     const uint64_t work = (uint64_t)p->numSparseEntries * K * batches;
     // the pass costs ~N*K, the halved gather saves ~entries*K: patterns with >= 11 entries per column repay it from
     // a third of the work (Trefethen_20000, 14 per column: K=128 15.3 -> 14.3 us, K=256 24.1 -> 22.0; wathen100,
@@ -1036,6 +1051,9 @@ int prepareDense(bsmr_plan* p, uint32_t K, int mode) {
         p->sharedB = choice.engine == BSMR_ENGINE_SHARED;
         p->tileGroupNow = choice.group;
         p->tileBlocksNow = choice.blocksPerItem;
+        p->formatNow = choice.format;
+        p->bOnlyNow = choice.bOnly;
+        p->overlapNow = choice.overlap;
     }
     if (!tilesEngine(p, K)) return BSMR_OK;
     return ensureTiles(p, chooseTileGroup(p, K));
@@ -1098,7 +1116,8 @@ int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P
         default: return launchSparse(p, K, A, B, P, q);
         }
     };
-    if ((which & 6) == 6 && p->overlap && dense != kNone && p->numSparseItems) {
+    const bool overlap = p->sideStream && (p->overlapNow >= 0 ? p->overlapNow == 1 : p->overlap);
+    if ((which & 6) == 6 && overlap && dense != kNone && p->numSparseItems) {
         // hybrid call: the residue kernel on the side stream beside the dense kernel (the reference runs its two
         // kernels on two streams, src/sddmmKernel.cu:2555-2559, 2576, 2618).  Fork behind the conversion, join on
         // the caller's stream.  Entries are disjoint, operands read-only: no ordering between the two is needed.
@@ -1477,7 +1496,6 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
                     delete p;
                     return st;
                 }
-                for (uint32_t h = 1; h <= bsmr::kTileMaxGroup; h *= 2) p->census[tileSlot(h)] = bsmr::tileCensus(p->hostDense, h);
             }
         }
         // full conversion moves 6 bytes per operand element; the in-kernel path reads each
@@ -1517,7 +1535,8 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
 
         // hybrid plans: side stream + events for the residue kernel beside the dense kernel
         if (st == BSMR_OK && pk.numBlocks && pk.numSparseEntries &&
-            (o.overlap_streams == 1 || (o.overlap_streams < 0 && pk.numDenseEntries >= (4u << 20) && pk.numSparseEntries >= (4u << 20)))) {
+            (o.overlap_streams == 1 || o.dense_engine == BSMR_ENGINE_TUNED ||
+             (o.overlap_streams < 0 && pk.numDenseEntries >= (4u << 20) && pk.numSparseEntries >= (4u << 20)))) {
             // (measured on MI355X: the fork / join through two events costs 7-15 us per call - cop20k-like with node
             // blocks, K=128: 51.3 us serial, 66.1 forked; 4096^2 delta=0.1 as the RPHM splits it, K=512: 70.8 vs 77.8 -
             // so by default only plans whose two kernels both run for ~100 us or more fork)
@@ -1525,7 +1544,9 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
                 !hipOk(hipEventCreateWithFlags(&p->forkEvent, hipEventDisableTiming), "hipEventCreate") ||
                 !hipOk(hipEventCreateWithFlags(&p->joinEvent, hipEventDisableTiming), "hipEventCreate"))
                 st = BSMR_ERR_HIP;
-            p->overlap = st == BSMR_OK;
+            // (a tunable plan gets the stream and the events so that bsmr_plan_tune can try both; untuned it follows the rule)
+            p->overlap = st == BSMR_OK && (o.overlap_streams == 1 || (o.overlap_streams < 0 && pk.numDenseEntries >= (4u << 20) &&
+                                                                      pk.numSparseEntries >= (4u << 20)));
         }
         p->buildMs[0] = rulesMs;
         p->buildMs[1] = packMs;
@@ -1533,8 +1554,10 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         const Clock::time_point tSecond = Clock::now();
         // second dense format (4 panels per group) for gather-bound calls
         // (only when it could ever be chosen: chooseFormat wants the ungrouped columns cut 2.5x)
-        if (st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8 &&
-            pk.unionColumns * 2 >= 5 * bsmr::countUnionColumns(d, 4)) {
+        // (a tunable plan keeps it from a 1.5x cut on: which of the two serves a (K, mode) is then measured)
+        const uint64_t grouped4 = st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8
+                                      ? bsmr::countUnionColumns(d, 4) : 0;
+        if (grouped4 && (pk.unionColumns * 2 >= 5 * grouped4 || (p->tunable && pk.unionColumns * 2 >= 3 * grouped4))) {
             bsmr::PackedPlan pk4;
             opt.group = 4;
             opt.blocksPerItem = o.dense_blocks_per_item > 0 ? o.dense_blocks_per_item : 32;
@@ -1642,7 +1665,7 @@ int bsmr_plan_dense_choice(const bsmr_plan* plan, uint32_t K, uint32_t* group_si
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (tilesEngine(plan, K)) {
         const uint32_t h = chooseTileGroup(plan, K);
-        const bsmr::TileCensus& c = plan->census[tileSlot(h)];
+        const bsmr::TileCensus& c = censusOf(plan, h);
         if (group_size) *group_size = h;
         if (tiles) *tiles = c.tiles;
         if (union_columns) *union_columns = c.unionColumns;
@@ -1808,61 +1831,104 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     if (!plan->tunable) return BSMR_ERR_INVALID_ARG;
-    bsmr_tune_report r{BSMR_ENGINE_STREAM, -1.f, -1.f, -1.f, 0, 0};
+    bsmr_tune_report r{};
+    r.chosen_engine = BSMR_ENGINE_STREAM;
+    r.stream_us = r.grouped_us = r.tiles_us = r.shared_us = -1.f;
+    r.chosen_b_only = r.chosen_overlap = -1;
+    r.fp32_residue_us = r.b_only_us = r.one_stream_us = r.two_streams_us = -1.f;
     BSMR_HIP(hipSetDevice(plan->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t key = ((uint64_t)K << 8) | (uint32_t)mode;
     bsmr_plan::Tuned best;
-    if (mode != BSMR_COMPUTE_F32 && plan->hostDense.entries() != 0 && tilesServeK(K) && !plan->convertInKernel) {
-        if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        BSMR_HIP(hipEventCreate(&e0));
-        if (!hipOk(hipEventCreate(&e1), "hipEventCreate")) {
-            (void)hipEventDestroy(e0);
-            return BSMR_ERR_HIP;
-        }
-        // the candidates: the streaming engine, the tiles engine with its own rules, and the shared-B engine over the
-        // group sizes and work-item lengths it serves at this K (its own rule first)
-        std::vector<bsmr_plan::Tuned> candidates = {{BSMR_ENGINE_STREAM, 0, 0}, {BSMR_ENGINE_TILES, 0, 0}, {BSMR_ENGINE_SHARED, 0, 0}};
-        const uint32_t sharedMaxH = std::min<uint32_t>(16u, 4u * (32u / (K / 32u)));
-        for (int h = 4; h <= (int)std::min<uint32_t>(8u, sharedMaxH); h *= 2)
-            for (const int blocks : {8, 16, 32}) candidates.push_back({BSMR_ENGINE_SHARED, h, blocks});
-        float bestUs = -1.f;
-        st = runPieces(plan, K, A, B, P, mode, s, 1);   // the converted operands every candidate reads
-        for (size_t c = 0; c < candidates.size() && st == BSMR_OK; ++c) {
-            plan->tuned[key] = candidates[c];
-            if (const int pst = prepareDense(plan, K, mode)) {
-                if (candidates[c].engine == BSMR_ENGINE_STREAM) st = pst;   // (an engine whose format cannot be built does not compete)
-                continue;
-            }
-            for (int i = 0; i < 3 && st == BSMR_OK; ++i) st = runPieces(plan, K, A, B, P, mode, s, 2);
-            hipError_t e = hipEventRecord(e0, s);
-            for (int i = 0; i < 10 && st == BSMR_OK; ++i) st = runPieces(plan, K, A, B, P, mode, s, 2);
-            if (e == hipSuccess) e = hipEventRecord(e1, s);
-            if (e == hipSuccess) e = hipEventSynchronize(e1);
-            float ms = 0.f;
-            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-            if (!hipOk(e, "event timing")) st = BSMR_ERR_HIP;
-            const float us = ms * 100.f;   // 10 launches, microseconds each
-            float& slot = candidates[c].engine == BSMR_ENGINE_STREAM ? r.stream_us : candidates[c].engine == BSMR_ENGINE_TILES ? r.tiles_us : r.shared_us;
-            const bool engineBest = slot < 0.f || us < slot;
-            if (engineBest) slot = us;
-            if (bestUs < 0.f || us < bestUs) {
-                bestUs = us;
-                best = candidates[c];
-            }
-        }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    BSMR_HIP(hipEventCreate(&e0));
+    if (!hipOk(hipEventCreate(&e1), "hipEventCreate")) {
         (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        if (st != BSMR_OK) {
-            plan->tuned.erase(key);
-            return st;
+        return BSMR_ERR_HIP;
+    }
+    struct Events {
+        hipEvent_t a, b;
+        ~Events() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    } events{e0, e1};
+    // microseconds per launch of the pieces `which` with the choice `c` (3 warm-up + 10 timed launches); < 0: c cannot run
+    auto timeChoice = [&](const bsmr_plan::Tuned& c, int which, float& us) -> int {
+        us = -1.f;
+        plan->tuned[key] = c;
+        if (const int pst = prepareDense(plan, K, mode)) return c.engine == BSMR_ENGINE_STREAM ? pst : BSMR_OK;
+        int rc = BSMR_OK;
+        if (needsWorkspace(plan, mode, K) && (rc = reserve(plan, K)) != BSMR_OK) return rc;
+        for (int i = 0; i < 3 && rc == BSMR_OK; ++i) rc = runPieces(plan, K, A, B, P, mode, s, which);
+        hipError_t e = hipEventRecord(e0, s);
+        for (int i = 0; i < 10 && rc == BSMR_OK; ++i) rc = runPieces(plan, K, A, B, P, mode, s, which);
+        if (e == hipSuccess) e = hipEventRecord(e1, s);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (!hipOk(e, "event timing")) return BSMR_ERR_HIP;
+        if (rc == BSMR_OK) us = ms * 100.f;
+        return rc;
+    };
+    const bool lowp = mode != BSMR_COMPUTE_F32;
+    // 1. the dense part: the streaming engine on either format, the tiles engine with its own rules, the shared-B engine
+    //    over the group sizes and work-item lengths it serves at this K
+    if (lowp && plan->fmt[0].numItems && !plan->convertInKernel) {
+        std::vector<bsmr_plan::Tuned> candidates = {{BSMR_ENGINE_STREAM, 0, 0, 0}};
+        if (plan->fmt[1].H) candidates.push_back({BSMR_ENGINE_STREAM, 0, 0, 1});
+        if (plan->hostDense.entries() != 0 && tilesServeK(K)) {
+            candidates.push_back({BSMR_ENGINE_TILES, 0, 0});
+            candidates.push_back({BSMR_ENGINE_SHARED, 0, 0});
+            const uint32_t sharedMaxH = std::min<uint32_t>(16u, 4u * (32u / (K / 32u)));
+            for (int h = 4; h <= (int)std::min<uint32_t>(8u, sharedMaxH); h *= 2)
+                for (const int blocks : {8, 16, 32}) candidates.push_back({BSMR_ENGINE_SHARED, h, blocks});
         }
+        if (candidates.size() > 1) {
+            if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;
+            st = runPieces(plan, K, A, B, P, mode, s, 1);   // the converted operands every candidate reads
+            float bestUs = -1.f;
+            for (size_t c = 0; c < candidates.size() && st == BSMR_OK; ++c) {
+                float us = -1.f;
+                st = timeChoice(candidates[c], 2, us);
+                if (st != BSMR_OK || us < 0.f) continue;
+                float& slot = candidates[c].engine == BSMR_ENGINE_TILES    ? r.tiles_us
+                              : candidates[c].engine == BSMR_ENGINE_SHARED ? r.shared_us
+                              : candidates[c].format == 1                  ? r.grouped_us
+                                                                           : r.stream_us;
+                if (slot < 0.f || us < slot) slot = us;
+                if (bestUs < 0.f || us < bestUs) {
+                    bestUs = us;
+                    best = candidates[c];
+                }
+            }
+        }
+    }
+    // 2. plans without a dense part: the fp32 residue kernel against converting B alone and reading 16-bit operands
+    if (st == BSMR_OK && lowp && plan->convertBOnly && (size_t)16 * (2u * K + bsmr::kSparseLdsPad16) <= 64 * 1024) {
+        bsmr_plan::Tuned c = best;
+        c.bOnly = 0;
+        st = timeChoice(c, 7, r.fp32_residue_us);
+        c.bOnly = 1;
+        if (st == BSMR_OK) st = timeChoice(c, 7, r.b_only_us);
+        if (st == BSMR_OK && r.fp32_residue_us >= 0.f && r.b_only_us >= 0.f) best.bOnly = r.b_only_us < r.fp32_residue_us ? 1 : 0;
+    }
+    // 3. hybrid plans: both kernels on the caller's stream against the residue kernel on the side stream
+    if (st == BSMR_OK && plan->sideStream && plan->fmt[0].numItems && plan->numSparseItems) {
+        bsmr_plan::Tuned c = best;
+        c.overlap = 0;
+        st = timeChoice(c, 7, r.one_stream_us);
+        c.overlap = 1;
+        if (st == BSMR_OK) st = timeChoice(c, 7, r.two_streams_us);
+        if (st == BSMR_OK && r.one_stream_us >= 0.f && r.two_streams_us >= 0.f) best.overlap = r.two_streams_us < r.one_stream_us ? 1 : 0;
+    }
+    if (st != BSMR_OK) {
+        plan->tuned.erase(key);
+        return st;
     }
     plan->tuned[key] = best;
     r.chosen_engine = best.engine;
-    r.chosen_group = best.group;
+    r.chosen_group = best.engine == BSMR_ENGINE_STREAM ? (best.format == 1 ? (int)plan->fmt[1].H : 1) : best.group;
     r.chosen_blocks_per_item = best.blocksPerItem;
+    r.chosen_b_only = best.bOnly;
+    r.chosen_overlap = best.overlap;
     // leave a complete result in P and the chosen engine's format in place
     if ((st = prepareDense(plan, K, mode)) != BSMR_OK) return st;
     if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;

@@ -44,8 +44,10 @@ class RphmDesc(C.Structure):
 
 
 class TuneReport(C.Structure):
-    _fields_ = [("chosen_engine", C.c_int32), ("stream_us", C.c_float), ("tiles_us", C.c_float), ("shared_us", C.c_float),
-                ("chosen_group", C.c_int32), ("chosen_blocks_per_item", C.c_int32)]
+    _fields_ = [("chosen_engine", C.c_int32), ("chosen_group", C.c_int32), ("chosen_blocks_per_item", C.c_int32),
+                ("stream_us", C.c_float), ("grouped_us", C.c_float), ("tiles_us", C.c_float), ("shared_us", C.c_float),
+                ("chosen_b_only", C.c_int32), ("fp32_residue_us", C.c_float), ("b_only_us", C.c_float),
+                ("chosen_overlap", C.c_int32), ("one_stream_us", C.c_float), ("two_streams_us", C.c_float)]
 
 
 class PlanBuildMs(C.Structure):
@@ -498,8 +500,11 @@ def plan_tune(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, mode=COMPUTE_F16
     (the plan must have been created with dense_engine = ENGINE_TUNED).  P holds the result afterwards."""
     r = TuneReport()
     _check(hip().bsmr_plan_tune(plan, K, A_ptr, B_ptr, P_ptr, mode, stream, C.byref(r)), "bsmr_plan_tune")
-    return {"chosen": ENGINE_NAMES[r.chosen_engine], "stream_us": round(r.stream_us, 2), "tiles_us": round(r.tiles_us, 2),
-            "shared_us": round(r.shared_us, 2), "group": r.chosen_group, "blocks_per_item": r.chosen_blocks_per_item}
+    out = {"chosen": ENGINE_NAMES[r.chosen_engine], "group": r.chosen_group, "blocks_per_item": r.chosen_blocks_per_item}
+    for name in ("stream_us", "grouped_us", "tiles_us", "shared_us", "fp32_residue_us", "b_only_us", "one_stream_us", "two_streams_us"):
+        out[name] = round(getattr(r, name), 2)
+    out["b_only"], out["overlap"] = r.chosen_b_only, r.chosen_overlap
+    return out
 
 
 def sddmm_batch(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, num_batches: int, mode=COMPUTE_F16, stream: int = 0):

@@ -205,17 +205,27 @@ typedef struct bsmr_plan_build_ms {
 } bsmr_plan_build_ms;
 int bsmr_plan_build_times(const bsmr_plan *plan, bsmr_plan_build_ms *out);
 
-/* Which dense engine is fastest for calls with this K and mode is measured, not modelled: bsmr_plan_tune times the
- * dense part of the plan under each engine on the caller's operands (HIP events on `stream`, a conversion pass first,
- * 3 warm-up + 10 timed launches each) and the plan uses the fastest for every later call with the same (K, mode).
+/* The per-call choices are measured, not modelled: bsmr_plan_tune times, on the caller's operands (HIP events on
+ * `stream`, 3 warm-up + 10 timed launches each), the dense part under each engine and format, for all-sparse plans the
+ * fp32 residue against the B-only conversion, for hybrid plans one stream against two - and the plan uses the fastest
+ * of each for every later call with the same (K, mode); the fitted rules (grouped format from 400 MB of gathers,
+ * b_only_work_m, overlap from 4 M entries a side) only serve calls that were never tuned.
  * Needs a plan created with dense_engine = BSMR_ENGINE_TUNED; P is overwritten with the (correct) result.  The
  * reference has no counterpart: it tunes (alpha, delta) per matrix by sweeping (src/sddmm.cu:62-118). */
 typedef struct bsmr_tune_report {
-    int32_t chosen_engine;                    /* BSMR_ENGINE_STREAM / _TILES / _SHARED */
-    float   stream_us, tiles_us, shared_us;   /* best dense-kernel time per launch of each engine; < 0: not measured
-                                                 (the engine does not serve this call, or only one engine does) */
-    int32_t chosen_group;                     /* panels per group / blocks per work item of the winner where they were */
-    int32_t chosen_blocks_per_item;           /* part of the search (the shared-B engine), else 0 = the engine's own rule */
+    int32_t chosen_engine;            /* BSMR_ENGINE_STREAM / _TILES / _SHARED */
+    int32_t chosen_group;             /* panels per group of the winner (streaming engine: 1, or 4 = the grouped format) */
+    int32_t chosen_blocks_per_item;   /* shared-B engine: blocks per work item where that was part of the search, else 0 */
+    /* best dense-kernel time per launch of each candidate family, microseconds; < 0: not measured (no such format,
+     * the engine does not serve this K, or nothing to choose from) */
+    float   stream_us, grouped_us, tiles_us, shared_us;
+    /* plans without a dense part: whole call with the fp32 residue kernel against B converted alone + 16-bit residue
+     * (replaces the b_only_work_m threshold for this (K, mode)); -1 / < 0: does not apply */
+    int32_t chosen_b_only;
+    float   fp32_residue_us, b_only_us;
+    /* hybrid plans: whole call on one stream against the residue kernel on the side stream; -1 / < 0: does not apply */
+    int32_t chosen_overlap;
+    float   one_stream_us, two_streams_us;
 } bsmr_tune_report;
 int bsmr_plan_tune(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev, float *P_dev, int mode, void *stream,
                    bsmr_tune_report *report /* may be NULL */);

@@ -782,12 +782,17 @@ def test_tuned_plans_measure_the_dense_engines(engine, oracle):
             report = engine.plan_tune(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), mode, 0)
             torch.cuda.synchronize()
             print(f"K={K} mode={mode}: {report}")
-            if K == 96:      # the tiles engines serve K in {32, 64, 128, 256, 512}: nothing to measure
-                assert report["chosen"] == "stream" and max(report["stream_us"], report["tiles_us"], report["shared_us"]) < 0
+            families = {"stream": "stream", "grouped": "stream", "tiles": "tiles", "shared": "shared"}
+            measured = {f: report[f + "_us"] for f in families if report[f + "_us"] >= 0}
+            if K == 96:      # the tiles engines serve K in {32, 64, 128, 256, 512}: only the two formats of the streaming engine
+                assert report["chosen"] == "stream" and report["tiles_us"] < 0 and report["shared_us"] < 0
             else:
                 assert min(report["stream_us"], report["tiles_us"], report["shared_us"]) > 0
-                best = min(("stream", "tiles", "shared"), key=lambda e: report[e + "_us"])
-                assert report["chosen"] == best
+            if measured:
+                best = min(measured, key=measured.get)
+                assert report["chosen"] == families[best]
+                assert (report["group"] > 1) == (best != "stream"), report
+            assert report["b_only"] == -1 and report["overlap"] == -1      # an all-dense plan
             # (bf16 at K = 512 on U[0,2) data is inside the reference's tolerance)
             for label, got in (("untuned", before), ("left by tune", tP.cpu().numpy())):
                 bad, first = oracle.check_data(want, got)
@@ -799,6 +804,36 @@ def test_tuned_plans_measure_the_dense_engines(engine, oracle):
             assert bad == 0, (K, "tuned", bad, first)
     finally:
         engine.plan_destroy(plan)
+    # whole-call choices: a hybrid plan (one stream or two), a plan without a dense part (fp32 residue or B converted alone)
+    for name, (r2, c2, ro2, ci2), delta, extra, field, times in (
+            ("hybrid", synth.community_graph(n=2048, avg_degree=48, communities=8, seed=5), 0.2,
+             dict(fold_dense_below=0, promote_average=0), "overlap", ("one_stream_us", "two_streams_us")),
+            ("all sparse", synth.wathen_pattern(nx=40, ny=40), 0.3, {}, "b_only", ("fp32_residue_us", "b_only_us"))):
+        csr2 = engine.CSR.from_arrays(r2, c2, ro2, ci2)
+        arrays2 = engine.Pipeline(csr2, alpha=0.3, delta=delta, device=-1).arrays()
+        st, plan2 = engine.plan_from_arrays(r2, c2, csr2.nnz, arrays2, device=0,
+                                            options=engine.plan_options(dense_engine=engine.ENGINE_TUNED, **extra))
+        assert st == engine.OK
+        stats = engine.PlanStats()
+        engine.hip().bsmr_plan_get_stats(plan2, stats)
+        K = 128
+        A, B = engine.make_data(r2 * K, 5489), engine.make_data(c2 * K, 5490)
+        tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+        tP = torch.full((csr2.nnz,), float("nan"), dtype=torch.float32, device=dev)
+        report = engine.plan_tune(plan2, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
+        print(f"{name}: dense {stats.num_dense_entries} residue {stats.num_sparse_entries} {report}")
+        if name == "hybrid":
+            assert stats.num_dense_entries and stats.num_sparse_entries
+        else:
+            assert stats.num_dense_entries == 0
+        assert min(report[t] for t in times) > 0
+        assert report[field] == (1 if report[times[1]] < report[times[0]] else 0)
+        tP.fill_(float("nan"))
+        engine.sddmm(plan2, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
+        torch.cuda.synchronize()
+        bad, first = oracle.check_data(oracle.sddmm_cpu(r2, c2, K, ro2, ci2, A, B), tP.cpu().numpy())
+        assert bad == 0, (name, bad, first)
+        engine.plan_destroy(plan2)
     st, plain = engine.plan_from_arrays(rows, cols, csr.nnz, arrays, device=0, options=engine.plan_options())
     assert st == engine.OK
     rep = engine.TuneReport()
