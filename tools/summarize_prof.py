@@ -44,7 +44,7 @@ for k, c in pmc.items():
         out["traffic_bytes_per_launch"] = traffic
         tfile = dst / "traffic.json"
         t = json.loads(tfile.read_text()) if tfile.exists() else {}
-        t[f"{workload}:{mode}:{dom}"] = {"bytes": traffic, "source": f"profiles/{rnd}_{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of the same bench command; 2 x FETCH_SIZE + WRITE_SIZE)"}
+        t[f"{workload}:{mode}:{dom}{bench['roofline'].get('engine_tag', '')}"] = {"bytes": traffic, "source": f"profiles/{rnd}_{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of the same bench command; 2 x FETCH_SIZE + WRITE_SIZE)"}
         tfile.write_text(json.dumps(t, indent=1))
 (dst / f"{rnd}_{tag}_pmc.json").write_text(json.dumps(out, indent=1))
 print(open(dst / f"{rnd}_{tag}_kernel_stats.csv").read()[:1500])
