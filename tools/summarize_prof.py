@@ -38,8 +38,10 @@ out = {"bench": {k: bench[k] for k in ("value", "ms_per_step", "kernels_ms", "ro
 # FETCH_SIZE counts half of a 16-B-per-lane stream (MI355X_MICROARCH.md "HBM"), so it is doubled.
 dom = bench["roofline"]["kernel"]
 names = {"dense": ("denseStream", "denseGroups", "denseTiles", "denseShared"), "sparse": ("sparseEntries",), "convert": ("convertOperands",)}[dom]
+# (a tuned run launches every candidate engine a few times: the steps' kernel is the one with the most launches)
+matching = [(c["FETCH_SIZE"]["launches"], k) for k, c in pmc.items() if any(n in k for n in names) and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
 for k, c in pmc.items():
-    if any(n in k for n in names) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    if matching and k == max(matching)[1]:
         traffic = int((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
         out["traffic_bytes_per_launch"] = traffic
         tfile = dst / "traffic.json"
