@@ -126,10 +126,11 @@ struct bsmr_plan {
         int format = -1;    // streaming engine: 0 = one panel per group, 1 = the grouped format, -1 = chooseFormat's rule
         int bOnly = -1;     // all-sparse plans: 1 = convert B alone and read 16-bit operands, 0 = fp32 residue, -1 = the rule
         int overlap = -1;   // hybrid plans: 1 = residue kernel on the side stream, 0 = one stream, -1 = as the plan was built
+        int cvt = -1;       // K = 32 / 64: 1 = fp32 operands rounded inside the dense kernel (no conversion pass), 0 = pass, -1 = the rule
     };
     std::map<uint64_t, Tuned> tuned;   // ... from what bsmr_plan_tune measured for (K << 8 | mode); untuned calls stream
     int tileGroupNow = 0, tileBlocksNow = 0;   // tuned group size / blocks per item of the call being prepared
-    int formatNow = -1, bOnlyNow = -1, overlapNow = -1;   // ... and its format / conversion / stream choices
+    int formatNow = -1, bOnlyNow = -1, overlapNow = -1, cvtNow = -1;   // ... and its format / conversion / stream choices
     bsmr_plan_options opt{};       // what the plan was built with
 
     // hybrid plans: the residue kernel runs on a side stream beside the dense kernel (reference
@@ -830,8 +831,25 @@ int launchTiles(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint1
     }
 }
 
+// fp32 -> 16-bit rounding inside the dense kernel instead of a conversion pass: the plan's rule (a tiny dense part), or
+// what bsmr_plan_tune measured for the call being prepared (K = 32 / 64: the streaming fp32 kernel against pass + kernel)
+// what the fp32-operand streaming kernel (denseStreamCvt) serves
+inline bool streamCvtServes(const DenseFormat& f, uint32_t K) {
+    return (K == 32 || K == 64) && f.H == 1 && f.maxItemBlocks <= 8 && (f.tiles8 || f.tilesM) && !f.stageInLds;
+}
+// Untuned, an all-dense plan also rounds in the kernel at K = 32 / 64 (measured, whole call: nips-like K=32 9.3 -> 7.4 us,
+// mycielskian14 K=32 13.3 -> 11.3, mycielskian15 K=32 26.7 -> 26.2; with a residue the choice is left to the tuner,
+// because the residue then runs its fp32 kernel).
+inline bool cvtInKernel(const bsmr_plan* p, uint32_t K) {
+    if (p->cvtNow >= 0) return p->cvtNow == 1;
+    return p->convertInKernel || (p->numSparseItems == 0 && p->useStream && streamCvtServes(p->fmt[0], K) && !p->useTiles);
+}
+inline bool convertPassOf(const bsmr_plan* p, uint32_t K) {
+    if (cvtInKernel(p, K)) return false;   // (the residue of such a call runs its fp32 kernel)
+    return p->fmt[0].numItems != 0 || p->convertPass;
+}
 inline bool tilesEngine(const bsmr_plan* p, uint32_t K) {
-    return p->useTiles && tilesServeK(K) && p->hostDense.entries() != 0 && !p->convertInKernel;
+    return p->useTiles && tilesServeK(K) && p->hostDense.entries() != 0 && !cvtInKernel(p, K);
 }
 
 template <int MODE>
@@ -881,10 +899,27 @@ int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uin
 }
 
 // fp32 operands, rounded to fp16 / bf16 in registers (small dense parts)
+// fp32 operands, K = 32 / 64, one panel per group, window tiles, items of <= 8 blocks: the streaming form
+template <int KS, int MODE, typename TileT>
+int launchStreamCvtT(const DenseFormat& f, const float* A, const float* B, const TileT* tiles, float* P, const Queue& s) {
+    auto kernel = bsmr::denseStreamCvt<KS, MODE, TileT>;
+    const size_t lds = (size_t)2 * 16u * 128u * KS;
+    hipLaunchKernelGGL(kernel, dim3(f.numItems, s.batch.count), dim3(bsmr::kWave), lds, s, A, B, f.groupRows, f.rowBase, f.blockCols,
+                       tiles, f.items, P, s.batch);
+    BSMR_HIP(hipGetLastError());
+    return BSMR_OK;
+}
+
 template <int MODE>
 int launchDenseCvt(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, const Queue& s) {
     const DenseFormat& f = p->fmt[0];
     if (f.numItems == 0) return BSMR_OK;
+    if (streamCvtServes(f, K) && p->useStream) {
+        if (K == 32) return f.tilesM ? launchStreamCvtT<1, MODE, bsmr::TileMask>(f, A, B, f.tilesM, P, s)
+                                     : launchStreamCvtT<1, MODE, uint8_t>(f, A, B, f.tiles8, P, s);
+        return f.tilesM ? launchStreamCvtT<2, MODE, bsmr::TileMask>(f, A, B, f.tilesM, P, s)
+                        : launchStreamCvtT<2, MODE, uint8_t>(f, A, B, f.tiles8, P, s);
+    }
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
     if (f.tilesM)
         hipLaunchKernelGGL((bsmr::denseGroupsCvt<MODE, bsmr::TileMask>), dim3(wgs, s.batch.count), dim3(bsmr::kThreads), 0, s, A, B, K,
@@ -1039,7 +1074,7 @@ inline bool convertsBOnly(const bsmr_plan* p, uint32_t K, uint32_t batches = 1) 
 }
 
 inline bool needsWorkspace(const bsmr_plan* p, int mode, uint32_t K, uint32_t batches = 1) {
-    return mode != BSMR_COMPUTE_F32 && (p->convertPass || convertsBOnly(p, K, batches));
+    return mode != BSMR_COMPUTE_F32 && (convertPassOf(p, K) || convertsBOnly(p, K, batches));
 }
 
 // device format of the dense part for calls with inner dimension K (allocates on first use)
@@ -1054,6 +1089,7 @@ int prepareDense(bsmr_plan* p, uint32_t K, int mode) {
         p->formatNow = choice.format;
         p->bOnlyNow = choice.bOnly;
         p->overlapNow = choice.overlap;
+        p->cvtNow = choice.cvt;
     }
     if (!tilesEngine(p, K)) return BSMR_OK;
     return ensureTiles(p, chooseTileGroup(p, K));
@@ -1086,9 +1122,9 @@ int runPieces(bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P
     } else if (convertsBOnly(p, K, s.batch.count)) {
         convertB = true;
         sparse = kSparse16FromFp32A;
-    } else if (p->convertInKernel) {
+    } else if (cvtInKernel(p, K)) {
         dense = kDenseCvt;
-    } else if (p->convertPass) {
+    } else if (convertPassOf(p, K)) {
         convertAll = true;
         dense = kDense16;
         if (p->sparseLowp) sparse = kSparse16;
@@ -1683,7 +1719,7 @@ int bsmr_plan_sparse_choice(const bsmr_plan* plan, uint32_t K, int mode, uint32_
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     const bool lowp = mode != BSMR_COMPUTE_F32 && plan->sparseLowp && plan->numSparseItems &&
-                      (plan->convertPass || convertsBOnly(plan, K));
+                      (convertPassOf(plan, K) || convertsBOnly(plan, K));
     if (lanes_per_entry) *lanes_per_entry = (uint32_t)sparseShape(plan, K, lowp).lpe;
     if (low_precision) *low_precision = lowp ? 1u : 0u;
     return BSMR_OK;
@@ -1706,7 +1742,7 @@ int bsmr_plan_reserve(bsmr_plan* plan, uint32_t K) {
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     BSMR_HIP(hipSetDevice(plan->device));
     if (int st = prepareDense(plan, K, BSMR_COMPUTE_F16)) return st;
-    if (!plan->convertPass && !convertsBOnly(plan, K)) return BSMR_OK;
+    if (!convertPassOf(plan, K) && !convertsBOnly(plan, K)) return BSMR_OK;
     return reserve(plan, K);
 }
 
@@ -1836,6 +1872,8 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
     r.stream_us = r.grouped_us = r.tiles_us = r.shared_us = -1.f;
     r.chosen_b_only = r.chosen_overlap = -1;
     r.fp32_residue_us = r.b_only_us = r.one_stream_us = r.two_streams_us = -1.f;
+    r.chosen_cvt_in_kernel = -1;
+    r.convert_pass_us = r.fp32_dense_us = -1.f;
     BSMR_HIP(hipSetDevice(plan->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t key = ((uint64_t)K << 8) | (uint32_t)mode;
@@ -1919,11 +1957,30 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
         if (st == BSMR_OK) st = timeChoice(c, 7, r.two_streams_us);
         if (st == BSMR_OK && r.one_stream_us >= 0.f && r.two_streams_us >= 0.f) best.overlap = r.two_streams_us < r.one_stream_us ? 1 : 0;
     }
+    // 4. K = 32 / 64: conversion pass + 16-bit kernels against the streaming kernel that reads the fp32 operands itself
+    //    (then the residue, if any, runs its fp32 kernel): whole call
+    if (st == BSMR_OK && lowp && plan->fmt[0].numItems && streamCvtServes(plan->fmt[0], K) && plan->useStream &&
+        !(plan->sparseLowp && plan->numSparseEntries > 10ull * ((uint64_t)plan->M + plan->N))) {
+        bsmr_plan::Tuned c = best;
+        c.cvt = 0;
+        st = timeChoice(c, 7, r.convert_pass_us);
+        bsmr_plan::Tuned f = best;
+        f.engine = BSMR_ENGINE_STREAM;
+        f.format = 0;
+        f.group = f.blocksPerItem = 0;
+        f.cvt = 1;
+        if (st == BSMR_OK) st = timeChoice(f, 7, r.fp32_dense_us);
+        if (st == BSMR_OK && r.convert_pass_us >= 0.f && r.fp32_dense_us >= 0.f) {
+            if (r.fp32_dense_us < r.convert_pass_us) best = f;
+            else best.cvt = 0;
+        }
+    }
     if (st != BSMR_OK) {
         plan->tuned.erase(key);
         return st;
     }
     plan->tuned[key] = best;
+    r.chosen_cvt_in_kernel = best.cvt;
     r.chosen_engine = best.engine;
     r.chosen_group = best.engine == BSMR_ENGINE_STREAM ? (best.format == 1 ? (int)plan->fmt[1].H : 1) : best.group;
     r.chosen_blocks_per_item = best.blocksPerItem;

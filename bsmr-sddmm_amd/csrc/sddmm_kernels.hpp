@@ -601,6 +601,125 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
 }
 
 // ---------------------------------------------------------------------------
+// streaming dense kernel on fp32 operands for K = 32 and 64 (KS = 1, 2): the conversion pass and the kernel boundary
+// behind it cost more than they save when a column is 128 or 256 bytes (nips-like K = 32: conversion 2.4 us + boundary
+// against a dense kernel of 6 us).  Same structure as denseStream in its one-wave form: the fp32 columns of a block
+// are gathered by LDS-DMA into a wave-private ring of two images (an image has the geometry of a 16-bit image of 2 K),
+// a lane reads its 8 consecutive k as two 16-byte pieces and rounds them to fp16 / bf16 in registers with the casts of
+// convertOperands (packLowp), so the MFMA operands - and the results - are bit for bit those of the two-kernel path.
+// ---------------------------------------------------------------------------
+template <int KS, int MODE, typename TileT, int MAXB = 8>
+__global__ void __launch_bounds__(kWave)
+denseStreamCvt(const float* __restrict__ A, const float* __restrict__ B, const uint32_t* __restrict__ groupRows,
+               const uint32_t* __restrict__ rowBaseTable, const uint32_t* __restrict__ blockCols,
+               const TileT* __restrict__ tiles, const DenseItem* __restrict__ items, float* __restrict__ P, Batch batch) {
+    static_assert(KS == 1 || KS == 2, "K = 32 or 64");
+    A += blockIdx.y * batch.strideA;
+    B += blockIdx.y * batch.strideB;
+    P += blockIdx.y * batch.strideP;
+    constexpr uint32_t K = 32u * KS;
+    constexpr uint32_t DMA = 2u * KS;                 // 1 KiB LDS-DMA instructions per image
+    constexpr uint32_t PC = 8u * KS;                  // 16-byte pieces per fp32 column
+    constexpr uint32_t SW = PC - 1u < 15u ? PC - 1u : 15u;
+    constexpr uint32_t rowBytes = 128u * KS;          // one column of an image
+    constexpr uint32_t blkBytes = 16u * rowBytes;     // one image
+    constexpr bool WINDOWED = TileLoad<TileT>::windowed;
+    constexpr uint32_t CREG = (MAXB + 3) / 4;
+    typedef typename TileLoad<TileT>::raw TileRaw;
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [2][blkBytes]
+    const uint32_t itemId = xcdContiguous(blockIdx.x, gridDim.x);
+    const DenseItem item = items[itemId];
+    const uint32_t lane = threadIdx.x & 63u, r = lane & 15u, g = lane >> 4;
+    const uint32_t myCount = min(item.count, (uint32_t)MAXB);
+    if (myCount == 0) return;
+    const uint32_t myFirst = item.first;
+
+    uint32_t cols[CREG];   // lane l, register q: column (l & 15) of block 4q + (l >> 4)
+#pragma unroll
+    for (uint32_t q = 0; q < CREG; ++q) cols[q] = blockCols[(size_t)(myFirst + min(4u * q + g, myCount - 1u)) * 16u + r];
+    const uint32_t rowSlot = item.group * 16u;
+    uint32_t myRow = groupRows[rowSlot + r];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (uint32_t q = 0; q < CREG; ++q) asm volatile("" : "+v"(cols[q]));
+    asm volatile("" : "+v"(myRow));
+
+    auto gather = [&](uint32_t m) {  // block m -> slot m % 2
+        uint8_t* dst = lds + (m & 1u) * blkBytes;
+#pragma unroll
+        for (int j = 0; j < (int)DMA; ++j) {
+            const uint32_t f = 64u * j + lane;
+            const uint32_t col = f / PC, t = f % PC;
+            const uint32_t cid = __shfl(cols[m >> 2], ((m & 3u) << 4) + col);
+            const float* src = B + (size_t)cid * K + ((t ^ (col & SW)) << 2);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)src,
+                (__attribute__((address_space(3))) void*)(dst + j * 1024u), 16, 0, 0);
+        }
+    };
+    auto waitForAllButNewestGather = [&]() {
+        if constexpr (DMA == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+
+    gather(0);
+    // the A rows of the panel as fp32 fragments (inline assembly: see denseStream), rounded once they have landed
+    f32x4 aLo[KS], aHi[KS];
+    {
+        const float* aRow = A + (size_t)myRow * K + g * 8u;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aLo[s]) : "v"(aRow + s * 32) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aHi[s]) : "v"(aRow + s * 32 + 4) : "memory");
+        }
+    }
+    TileRaw tile[MAXB];
+#pragma unroll
+    for (uint32_t m = 0; m < (uint32_t)MAXB; ++m)
+        if (m < myCount) tile[m] = loadTile<TileT>(tiles, (size_t)(myFirst + m), lane);
+    uint32_t rowBase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        rowBase[i] = WINDOWED ? rowBaseTable[(size_t)itemId * 16u + 4u * g + i] : rowBaseTable[rowSlot + 4u * g + i];
+
+    f32x4 acc[MAXB];
+    u32x4 a[KS];
+#pragma unroll
+    for (uint32_t m = 0; m < (uint32_t)MAXB; ++m) {
+        if (m >= myCount) break;  // wave-uniform
+        if (m + 1 < myCount) {
+            gather(m + 1);
+            waitForAllButNewestGather();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (m == 0) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                asm volatile("" : "+v"(aLo[s]));
+                asm volatile("" : "+v"(aHi[s]));
+                a[s] = packLowp<MODE>(aLo[s], aHi[s]);
+            }
+        }
+        const uint8_t* bCol = lds + (m & 1u) * blkBytes + r * rowBytes;
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const uint32_t p0 = 8u * s + 2u * g;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(bCol + ((p0 ^ (r & SW)) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(bCol + (((p0 + 1u) ^ (r & SW)) << 4));
+            c = mfma16<MODE>(a[s], packLowp<MODE>(lo, hi), c);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        acc[m] = c;
+    }
+#pragma unroll
+    for (uint32_t m = 0; m < (uint32_t)MAXB; ++m)
+        if (m < myCount) scatterTile<TileT>(acc[m], tile[m], rowBase, P);
+}
+
+// ---------------------------------------------------------------------------
 // dense fallback, 16-bit operands, any K (multiple of 32): fragments straight
 // from global memory, run-time K loop.  One wave per DenseItem.
 // ---------------------------------------------------------------------------

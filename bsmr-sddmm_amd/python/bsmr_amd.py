@@ -47,7 +47,8 @@ class TuneReport(C.Structure):
     _fields_ = [("chosen_engine", C.c_int32), ("chosen_group", C.c_int32), ("chosen_blocks_per_item", C.c_int32),
                 ("stream_us", C.c_float), ("grouped_us", C.c_float), ("tiles_us", C.c_float), ("shared_us", C.c_float),
                 ("chosen_b_only", C.c_int32), ("fp32_residue_us", C.c_float), ("b_only_us", C.c_float),
-                ("chosen_overlap", C.c_int32), ("one_stream_us", C.c_float), ("two_streams_us", C.c_float)]
+                ("chosen_overlap", C.c_int32), ("one_stream_us", C.c_float), ("two_streams_us", C.c_float),
+                ("chosen_cvt_in_kernel", C.c_int32), ("convert_pass_us", C.c_float), ("fp32_dense_us", C.c_float)]
 
 
 class PlanBuildMs(C.Structure):
@@ -501,9 +502,9 @@ def plan_tune(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, mode=COMPUTE_F16
     r = TuneReport()
     _check(hip().bsmr_plan_tune(plan, K, A_ptr, B_ptr, P_ptr, mode, stream, C.byref(r)), "bsmr_plan_tune")
     out = {"chosen": ENGINE_NAMES[r.chosen_engine], "group": r.chosen_group, "blocks_per_item": r.chosen_blocks_per_item}
-    for name in ("stream_us", "grouped_us", "tiles_us", "shared_us", "fp32_residue_us", "b_only_us", "one_stream_us", "two_streams_us"):
+    for name in ("stream_us", "grouped_us", "tiles_us", "shared_us", "fp32_residue_us", "b_only_us", "one_stream_us", "two_streams_us", "convert_pass_us", "fp32_dense_us"):
         out[name] = round(getattr(r, name), 2)
-    out["b_only"], out["overlap"] = r.chosen_b_only, r.chosen_overlap
+    out["b_only"], out["overlap"], out["cvt_in_kernel"] = r.chosen_b_only, r.chosen_overlap, r.chosen_cvt_in_kernel
     return out
 
 

@@ -226,6 +226,10 @@ typedef struct bsmr_tune_report {
     /* hybrid plans: whole call on one stream against the residue kernel on the side stream; -1 / < 0: does not apply */
     int32_t chosen_overlap;
     float   one_stream_us, two_streams_us;
+    /* K = 32 / 64: whole call with the conversion pass against the streaming dense kernel that reads the fp32 operands and
+     * rounds them in registers (same results); -1 / < 0: does not apply */
+    int32_t chosen_cvt_in_kernel;
+    float   convert_pass_us, fp32_dense_us;
 } bsmr_tune_report;
 int bsmr_plan_tune(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev, float *P_dev, int mode, void *stream,
                    bsmr_tune_report *report /* may be NULL */);

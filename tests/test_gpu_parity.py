@@ -771,7 +771,8 @@ def test_tuned_plans_measure_the_dense_engines(engine, oracle):
     assert st == engine.OK
     dev = _dev()
     try:
-        for K, mode in ((128, engine.COMPUTE_F16), (512, engine.COMPUTE_BF16), (96, engine.COMPUTE_F16)):
+        for K, mode in ((128, engine.COMPUTE_F16), (512, engine.COMPUTE_BF16), (96, engine.COMPUTE_F16), (64, engine.COMPUTE_F16),
+                        (32, engine.COMPUTE_F16)):
             A, B = engine.make_data(rows * K, 5489), engine.make_data(cols * K, 5490)
             want = oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B)
             tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
@@ -788,11 +789,18 @@ def test_tuned_plans_measure_the_dense_engines(engine, oracle):
                 assert report["chosen"] == "stream" and report["tiles_us"] < 0 and report["shared_us"] < 0
             else:
                 assert min(report["stream_us"], report["tiles_us"], report["shared_us"]) > 0
-            if measured:
+            if measured and report["cvt_in_kernel"] == 1:     # the fp32-operand kernel is a streaming kernel
+                assert report["chosen"] == "stream"
+            elif measured:
                 best = min(measured, key=measured.get)
                 assert report["chosen"] == families[best]
                 assert (report["group"] > 1) == (best == "grouped") or best in ("tiles", "shared"), report
             assert report["b_only"] == -1 and report["overlap"] == -1      # an all-dense plan
+            if K in (32, 64):    # conversion pass + 16-bit kernel against the fp32-operand streaming kernel: whole call
+                assert min(report["convert_pass_us"], report["fp32_dense_us"]) > 0
+                assert report["cvt_in_kernel"] == (1 if report["fp32_dense_us"] < report["convert_pass_us"] else 0)
+            else:
+                assert report["cvt_in_kernel"] == -1
             # (bf16 at K = 512 on U[0,2) data is inside the reference's tolerance)
             for label, got in (("untuned", before), ("left by tune", tP.cpu().numpy())):
                 bad, first = oracle.check_data(want, got)
@@ -839,6 +847,42 @@ def test_tuned_plans_measure_the_dense_engines(engine, oracle):
     rep = engine.TuneReport()
     assert engine.hip().bsmr_plan_tune(plain, 128, 1, 1, 1, engine.COMPUTE_F16, 0, rep) == engine.ERR_INVALID_ARG
     engine.plan_destroy(plain)
+
+
+@pytest.mark.shipping_rules
+@pytest.mark.parametrize("K", [32, 64])
+@pytest.mark.parametrize("mask_tiles", [0, 1])
+def test_fp32_operand_streaming_kernel_equals_the_conversion_pass(engine, oracle, K, mask_tiles):
+    """K = 32 / 64 with convert_in_kernel = 1: the streaming dense kernel gathers the fp32 columns itself and rounds
+    them in registers with the conversion pass's casts - the same MFMA operands in the same order, so P is bit for bit
+    what conversion pass + 16-bit kernel give (and inside the reference's tolerance of the CPU oracle); the residue of
+    a hybrid plan then runs its fp32 kernel."""
+    rows, cols, ro, ci = synth.nips_like(rows=640, cols=3000, nnz=120000, seed=3)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    dev = _dev()
+    A, B = engine.make_data(rows * K, 5489), engine.make_data(cols * K, 5490)
+    tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    want = oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B)
+    for delta in (0.0, 0.3):
+        arrays = engine.Pipeline(csr, alpha=0.3, delta=delta, device=-1).arrays()
+        got = {}
+        for cvt in (0, 1):
+            st, plan = engine.plan_from_arrays(rows, cols, csr.nnz, arrays, device=0, options=engine.plan_options(
+                convert_in_kernel=cvt, mask_tiles=mask_tiles, fold_dense_below=0, promote_average=0, sparse_lowp=0))
+            assert st == engine.OK
+            stats = engine.PlanStats()
+            engine.hip().bsmr_plan_get_stats(plan, stats)
+            assert stats.num_dense_entries > 0 and (delta == 0.0 or stats.num_sparse_entries > 0)
+            for mode in (engine.COMPUTE_F16, engine.COMPUTE_BF16):
+                tP = torch.full((csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+                engine.sddmm(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), mode, 0)
+                torch.cuda.synchronize()
+                got[(cvt, mode)] = tP.cpu().numpy()
+            engine.plan_destroy(plan)
+        for mode in (engine.COMPUTE_F16, engine.COMPUTE_BF16):
+            assert np.array_equal(got[(0, mode)], got[(1, mode)]), (delta, mode)
+        bad, first = oracle.check_data(want, got[(1, engine.COMPUTE_F16)])
+        assert bad == 0, (delta, bad, first)
 
 
 def test_two_plans_on_two_devices_in_one_process(engine, oracle):

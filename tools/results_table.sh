@@ -30,6 +30,7 @@ for wl in [w.split(":")[0] for w in wls]:
     if e.get("blocks_per_item"): tuned += f" ({e['blocks_per_item']} blocks/item)"
     if e.get("b_only", -1) >= 0: tuned = "B-only conversion" if e["b_only"] else "fp32 residue"
     if e.get("overlap", -1) >= 0: tuned += ", two streams" if e["overlap"] else ", one stream"
+    if e.get("cvt_in_kernel", -1) == 1: tuned = "fp32 operands rounded in the dense kernel"
     print(f"| {wl} | {d['dtype']} | {d['ms_per_step'] * 1e3:.1f} | {d['value']:.0f} | {pub['gflops'] if pub else '-'} | {d['vs_baseline'] if d['vs_baseline'] else '-'} | "
           f"{k['convert_ms'] * 1e3:.1f} / {k['dense_ms'] * 1e3:.1f} / {k['sparse_ms'] * 1e3:.1f} | {r['kernel']}: {r['achieved']:.0f} ({r['frac']:.3f}) | {(str(round(pre['ms_per_step'] * 1e3, 1))) if pre else '-'} | "
           f"{c.get('value', '-')} ({c.get('cores', '-')}) | {d.get('parity_mismatches_vs_cpu', '-')} | {tuned} |")
