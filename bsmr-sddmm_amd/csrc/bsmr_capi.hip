@@ -837,12 +837,14 @@ int launchTiles(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint1
 inline bool streamCvtServes(const DenseFormat& f, uint32_t K) {
     return (K == 32 || K == 64) && f.H == 1 && f.maxItemBlocks <= 8 && (f.tiles8 || f.tilesM) && !f.stageInLds;
 }
-// Untuned, an all-dense plan also rounds in the kernel at K = 32 / 64 (measured, whole call: nips-like K=32 9.3 -> 7.4 us,
-// mycielskian14 K=32 13.3 -> 11.3, mycielskian15 K=32 26.7 -> 26.2; with a residue the choice is left to the tuner,
-// because the residue then runs its fp32 kernel).
+// Untuned, an all-dense plan whose gather stays small also rounds in the kernel at K = 32 / 64 (measured, whole call:
+// nips-like K=32 9.3 -> 7.4 us, mycielskian14 K=32 13.3 -> 11.3; mycielskian15 K=32, 1.8 M gathered columns: 26.6 vs
+// 27.1 in the bench loop; with a residue the choice is left to the tuner, because the residue then runs its fp32 kernel).
 inline bool cvtInKernel(const bsmr_plan* p, uint32_t K) {
     if (p->cvtNow >= 0) return p->cvtNow == 1;
-    return p->convertInKernel || (p->numSparseItems == 0 && p->useStream && streamCvtServes(p->fmt[0], K) && !p->useTiles);
+    // (the fp32 gather moves unionColumns x K x 2 bytes more, at ~12 TB/s, against ~4.5 us of pass + boundary saved)
+    return p->convertInKernel || (p->numSparseItems == 0 && p->useStream && streamCvtServes(p->fmt[0], K) && !p->useTiles &&
+                                  p->fmt[0].unionColumns * (uint64_t)K * 2ull <= (64ull << 20));
 }
 inline bool convertPassOf(const bsmr_plan* p, uint32_t K) {
     if (cvtInKernel(p, K)) return false;   // (the residue of such a call runs its fp32 kernel)
