@@ -1866,6 +1866,7 @@ int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B
 
 int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode, void* stream,
                    bsmr_tune_report* report) {
+    constexpr float kTuneMargin = 0.98f;   // what the untuned rules choose stays unless an alternative is 2 % faster
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     if (!plan->tunable) return BSMR_ERR_INVALID_ARG;
@@ -1934,7 +1935,8 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
                               : candidates[c].format == 1                  ? r.grouped_us
                                                                            : r.stream_us;
                 if (slot < 0.f || us < slot) slot = us;
-                if (bestUs < 0.f || us < bestUs) {
+                // (the first candidate is what the rules launch: another one has to beat the best so far by 2 %)
+                if (bestUs < 0.f || us < bestUs * kTuneMargin) {
                     bestUs = us;
                     best = candidates[c];
                 }
@@ -1948,7 +1950,11 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
         st = timeChoice(c, 7, r.fp32_residue_us);
         c.bOnly = 1;
         if (st == BSMR_OK) st = timeChoice(c, 7, r.b_only_us);
-        if (st == BSMR_OK && r.fp32_residue_us >= 0.f && r.b_only_us >= 0.f) best.bOnly = r.b_only_us < r.fp32_residue_us ? 1 : 0;
+        if (st == BSMR_OK && r.fp32_residue_us >= 0.f && r.b_only_us >= 0.f) {
+            plan->bOnlyNow = -1;
+            const bool rule = convertsBOnly(plan, K);
+            best.bOnly = rule ? (r.fp32_residue_us < r.b_only_us * kTuneMargin ? 0 : 1) : (r.b_only_us < r.fp32_residue_us * kTuneMargin ? 1 : 0);
+        }
     }
     // 3. hybrid plans: both kernels on the caller's stream against the residue kernel on the side stream
     if (st == BSMR_OK && plan->sideStream && plan->fmt[0].numItems && plan->numSparseItems) {
@@ -1957,7 +1963,9 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
         st = timeChoice(c, 7, r.one_stream_us);
         c.overlap = 1;
         if (st == BSMR_OK) st = timeChoice(c, 7, r.two_streams_us);
-        if (st == BSMR_OK && r.one_stream_us >= 0.f && r.two_streams_us >= 0.f) best.overlap = r.two_streams_us < r.one_stream_us ? 1 : 0;
+        if (st == BSMR_OK && r.one_stream_us >= 0.f && r.two_streams_us >= 0.f)
+            best.overlap = plan->overlap ? (r.one_stream_us < r.two_streams_us * kTuneMargin ? 0 : 1)
+                                         : (r.two_streams_us < r.one_stream_us * kTuneMargin ? 1 : 0);
     }
     // 4. K = 32 / 64: conversion pass + 16-bit kernels against the streaming kernel that reads the fp32 operands itself
     //    (then the residue, if any, runs its fp32 kernel): whole call
@@ -1973,7 +1981,10 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
         f.cvt = 1;
         if (st == BSMR_OK) st = timeChoice(f, 7, r.fp32_dense_us);
         if (st == BSMR_OK && r.convert_pass_us >= 0.f && r.fp32_dense_us >= 0.f) {
-            if (r.fp32_dense_us < r.convert_pass_us) best = f;
+            plan->cvtNow = -1;
+            const bool rule = cvtInKernel(plan, K);
+            const bool inKernel = rule ? !(r.convert_pass_us < r.fp32_dense_us * kTuneMargin) : r.fp32_dense_us < r.convert_pass_us * kTuneMargin;
+            if (inKernel) best = f;
             else best.cvt = 0;
         }
     }

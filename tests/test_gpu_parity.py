@@ -793,12 +793,14 @@ def test_tuned_plans_measure_the_dense_engines(engine, oracle):
                 assert report["chosen"] == "stream"
             elif measured:
                 best = min(measured, key=measured.get)
-                assert report["chosen"] == families[best]
+                mine = min(t for f, t in measured.items() if families[f] == report["chosen"])
+                assert report["chosen"] == families[best] or mine <= measured[best] * 1.03, report
                 assert (report["group"] > 1) == (best == "grouped") or best in ("tiles", "shared"), report
             assert report["b_only"] == -1 and report["overlap"] == -1      # an all-dense plan
             if K in (32, 64):    # conversion pass + 16-bit kernel against the fp32-operand streaming kernel: whole call
                 assert min(report["convert_pass_us"], report["fp32_dense_us"]) > 0
-                assert report["cvt_in_kernel"] == (1 if report["fp32_dense_us"] < report["convert_pass_us"] else 0)
+                chosen, other = ("fp32_dense_us", "convert_pass_us") if report["cvt_in_kernel"] == 1 else ("convert_pass_us", "fp32_dense_us")
+                assert report["cvt_in_kernel"] in (0, 1) and report[chosen] <= report[other] * 1.03    # (the rules' choice keeps a 2 % margin)
             else:
                 assert report["cvt_in_kernel"] == -1
             # (bf16 at K = 512 on U[0,2) data is inside the reference's tolerance)
@@ -835,7 +837,8 @@ def test_tuned_plans_measure_the_dense_engines(engine, oracle):
         else:
             assert stats.num_dense_entries == 0
         assert min(report[t] for t in times) > 0
-        assert report[field] == (1 if report[times[1]] < report[times[0]] else 0)
+        assert report[field] in (0, 1)
+        assert report[times[report[field]]] <= report[times[1 - report[field]]] * 1.03, report   # (2 % margin for the rules' choice)
         tP.fill_(float("nan"))
         engine.sddmm(plan2, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
         torch.cuda.synchronize()
