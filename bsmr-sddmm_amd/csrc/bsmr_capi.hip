@@ -835,7 +835,7 @@ int launchTiles(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint1
 // what bsmr_plan_tune measured for the call being prepared (K = 32 / 64: the streaming fp32 kernel against pass + kernel)
 // what the fp32-operand streaming kernel (denseStreamCvt) serves
 inline bool streamCvtServes(const DenseFormat& f, uint32_t K) {
-    return (K == 32 || K == 64) && f.H == 1 && f.maxItemBlocks <= 8 && (f.tiles8 || f.tilesM) && !f.stageInLds;
+    return (K == 32 || K == 64 || K == 128) && f.H == 1 && f.maxItemBlocks <= 8 && (f.tiles8 || f.tilesM) && !f.stageInLds;
 }
 // Untuned, an all-dense plan whose gather stays small also rounds in the kernel at K = 32 / 64 (measured, whole call:
 // nips-like K=32 9.3 -> 7.4 us, mycielskian14 K=32 13.3 -> 11.3; mycielskian15 K=32, 1.8 M gathered columns: 26.6 vs
@@ -843,7 +843,7 @@ inline bool streamCvtServes(const DenseFormat& f, uint32_t K) {
 inline bool cvtInKernel(const bsmr_plan* p, uint32_t K) {
     if (p->cvtNow >= 0) return p->cvtNow == 1;
     // (the fp32 gather moves unionColumns x K x 2 bytes more, at ~12 TB/s, against ~4.5 us of pass + boundary saved)
-    return p->convertInKernel || (p->numSparseItems == 0 && p->useStream && streamCvtServes(p->fmt[0], K) && !p->useTiles &&
+    return p->convertInKernel || (K <= 64 && p->numSparseItems == 0 && p->useStream && streamCvtServes(p->fmt[0], K) && !p->useTiles &&
                                   p->fmt[0].unionColumns * (uint64_t)K * 2ull <= (64ull << 20));
 }
 inline bool convertPassOf(const bsmr_plan* p, uint32_t K) {
@@ -919,8 +919,10 @@ int launchDenseCvt(const bsmr_plan* p, uint32_t K, const float* A, const float* 
     if (streamCvtServes(f, K) && p->useStream) {
         if (K == 32) return f.tilesM ? launchStreamCvtT<1, MODE, bsmr::TileMask>(f, A, B, f.tilesM, P, s)
                                      : launchStreamCvtT<1, MODE, uint8_t>(f, A, B, f.tiles8, P, s);
-        return f.tilesM ? launchStreamCvtT<2, MODE, bsmr::TileMask>(f, A, B, f.tilesM, P, s)
-                        : launchStreamCvtT<2, MODE, uint8_t>(f, A, B, f.tiles8, P, s);
+        if (K == 64) return f.tilesM ? launchStreamCvtT<2, MODE, bsmr::TileMask>(f, A, B, f.tilesM, P, s)
+                                     : launchStreamCvtT<2, MODE, uint8_t>(f, A, B, f.tiles8, P, s);
+        return f.tilesM ? launchStreamCvtT<4, MODE, bsmr::TileMask>(f, A, B, f.tilesM, P, s)
+                        : launchStreamCvtT<4, MODE, uint8_t>(f, A, B, f.tiles8, P, s);
     }
     const uint32_t wgs = (f.numItems + bsmr::kWavesPerWG - 1) / bsmr::kWavesPerWG;
     if (f.tilesM)

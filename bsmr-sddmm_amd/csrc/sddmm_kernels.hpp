@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(kWave)
 denseStreamCvt(const float* __restrict__ A, const float* __restrict__ B, const uint32_t* __restrict__ groupRows,
                const uint32_t* __restrict__ rowBaseTable, const uint32_t* __restrict__ blockCols,
                const TileT* __restrict__ tiles, const DenseItem* __restrict__ items, float* __restrict__ P, Batch batch) {
-    static_assert(KS == 1 || KS == 2, "K = 32 or 64");
+    static_assert(KS == 1 || KS == 2 || KS == 4, "K = 32, 64 or 128");
     A += blockIdx.y * batch.strideA;
     B += blockIdx.y * batch.strideB;
     P += blockIdx.y * batch.strideP;
@@ -660,7 +660,8 @@ denseStreamCvt(const float* __restrict__ A, const float* __restrict__ B, const u
     };
     auto waitForAllButNewestGather = [&]() {
         if constexpr (DMA == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if constexpr (DMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     };
 
     gather(0);

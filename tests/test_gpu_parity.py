@@ -797,7 +797,7 @@ def test_tuned_plans_measure_the_dense_engines(engine, oracle):
                 assert report["chosen"] == families[best] or mine <= measured[best] * 1.03, report
                 assert (report["group"] > 1) == (best == "grouped") or best in ("tiles", "shared"), report
             assert report["b_only"] == -1 and report["overlap"] == -1      # an all-dense plan
-            if K in (32, 64):    # conversion pass + 16-bit kernel against the fp32-operand streaming kernel: whole call
+            if K in (32, 64, 128):    # conversion pass + 16-bit kernel against the fp32-operand streaming kernel: whole call
                 assert min(report["convert_pass_us"], report["fp32_dense_us"]) > 0
                 chosen, other = ("fp32_dense_us", "convert_pass_us") if report["cvt_in_kernel"] == 1 else ("convert_pass_us", "fp32_dense_us")
                 assert report["cvt_in_kernel"] in (0, 1) and report[chosen] <= report[other] * 1.03    # (the rules' choice keeps a 2 % margin)
@@ -853,10 +853,10 @@ def test_tuned_plans_measure_the_dense_engines(engine, oracle):
 
 
 @pytest.mark.shipping_rules
-@pytest.mark.parametrize("K", [32, 64])
+@pytest.mark.parametrize("K", [32, 64, 128])
 @pytest.mark.parametrize("mask_tiles", [0, 1])
 def test_fp32_operand_streaming_kernel_equals_the_conversion_pass(engine, oracle, K, mask_tiles):
-    """K = 32 / 64 with convert_in_kernel = 1: the streaming dense kernel gathers the fp32 columns itself and rounds
+    """K = 32 / 64 / 128 with convert_in_kernel = 1: the streaming dense kernel gathers the fp32 columns itself and rounds
     them in registers with the conversion pass's casts - the same MFMA operands in the same order, so P is bit for bit
     what conversion pass + 16-bit kernel give (and inside the reference's tolerance of the CPU oracle); the residue of
     a hybrid plan then runs its fp32 kernel."""
