@@ -1594,10 +1594,11 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         const Clock::time_point tSecond = Clock::now();
         // second dense format (4 panels per group) for gather-bound calls
         // (only when it could ever be chosen: chooseFormat wants the ungrouped columns cut 2.5x)
-        // (a tunable plan keeps it from a 1.5x cut on: which of the two serves a (K, mode) is then measured)
+        // (packing it costs as much as the first format did on the host: only where grouping cuts the gathers 2.5x - the
+        // cases in which it has ever won; for a tunable plan bsmr_plan_tune then measures which of the two serves a (K, mode))
         const uint64_t grouped4 = st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8
                                       ? bsmr::countUnionColumns(d, 4) : 0;
-        if (grouped4 && (pk.unionColumns * 2 >= 5 * grouped4 || (p->tunable && pk.unionColumns * 2 >= 3 * grouped4))) {
+        if (grouped4 && pk.unionColumns * 2 >= 5 * grouped4) {
             bsmr::PackedPlan pk4;
             opt.group = 4;
             opt.blocksPerItem = o.dense_blocks_per_item > 0 ? o.dense_blocks_per_item : 32;
