@@ -526,7 +526,7 @@ def test_medium_scale_properties(engine, oracle):
         assert st["num_dense_entries"] + st["num_sparse_entries"] == ci.size
 
 
-@pytest.mark.parametrize("K,delta,mode", [(32, 0.1, 0), (128, 0.0, 0), (128, 0.3, 1), (64, 0.1, 2), (96, 0.1, 0)])
+@pytest.mark.parametrize("K,delta,mode", [(32, 0.1, 0), (128, 0.0, 0), (128, 0.3, 1), (64, 0.1, 2), (96, 0.1, 0), (32, 0.0, 0), (64, 0.0, 1)])
 def test_batched_sddmm_equals_single_calls(engine, oracle, K, delta, mode):
     """bsmr_sddmm_batch (sddmm_gpu_batch of the reference): num_batches problems over one plan, A / B / P
     stored back to back; every batch equals the single call on its operands, bit for bit."""
