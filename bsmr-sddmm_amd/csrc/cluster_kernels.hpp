@@ -253,22 +253,23 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
                 } else {
                     const uint32_t* rep = reps + (size_t)sSlot[j].rep * numBins;
                     const double normRep = (double)sqrtf((float)sqRep), normRow = (double)sqrtf((float)sqRow);
-                    double minSum = 0.0, maxShared = 0.0, repInRow = 0.0;  // counts < 2^53: exact in double
+                    // min + max = x + y in every bin, so  sum max = |x|_1 + |y|_1 - sum min: only the min-sum and the
+                    // row's own |y|_1 are accumulated, with reciprocals instead of two divisions per bin (the value is
+                    // only compared with alpha, and anything within 1e-4 of it is evaluated exactly below)
+                    const double invRep = 1.0 / normRep, invRow = 1.0 / normRow;
+                    double minSum = 0.0, sumY = 0.0;
                     for (uint32_t i = encOffsets[row] + lane; i < encOffsets[row + 1]; i += lanes) {
                         const uint32_t bin = encBins[i];
                         if (!binCounts(bin, T, liveWarps)) continue;
-                        const uint32_t c = rep[bin];
-                        const double x = (double)c / normRep, y = (double)encCounts[i] / normRow;
+                        const double x = (double)rep[bin] * invRep, y = (double)encCounts[i] * invRow;
                         minSum += x < y ? x : y;
-                        maxShared += x < y ? y : x;
-                        repInRow += (double)c;
+                        sumY += y;
                     }
                     for (uint32_t w = lanes >> 1; w >= 1; w >>= 1) {
                         minSum += __shfl_xor(minSum, w, 64);
-                        maxShared += __shfl_xor(maxShared, w, 64);
-                        repInRow += __shfl_xor(repInRow, w, 64);
+                        sumY += __shfl_xor(sumY, w, 64);
                     }
-                    const double approx = minSum / (maxShared + ((double)sSlot[j].total - repInRow) / normRep);
+                    const double approx = minSum / ((double)sSlot[j].total * invRep + sumY - minSum);
                     const double margin = approx - (double)alpha;
                     if (margin > 1e-4) hit = true;
                     else if (margin >= -1e-4) near = true;
