@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "bsmr_hip.h"
@@ -27,7 +28,10 @@
 namespace bsmr {
 
 struct PromotedRphm {
-    std::vector<uint32_t> denseCols, blockOffsets, blockValues;
+    std::vector<uint32_t> denseCols, blockOffsets;
+    // (1 KiB per block: allocated without a fill and written once, panel by panel, by the workers - a vector's
+    // single-threaded fill of 0.5 GB was a third of this step on the reddit-like shard)
+    std::unique_ptr<uint32_t[]> blockValues;
     std::vector<uint32_t> sparseOffsets, sparseValues, sparseRows, sparseCols;
     bsmr_rphm_desc desc{};
     uint64_t promotedEntries = 0, promotedBlocks = 0;
@@ -152,7 +156,7 @@ inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, u
     }
     const uint64_t blocks = out.blockOffsets[P];
     out.denseCols.resize(blocks * 16);
-    out.blockValues.assign(blocks * 256, kNone);
+    out.blockValues.reset(new uint32_t[std::max<uint64_t>(blocks * 256, 1)]);
     out.sparseValues.resize(out.sparseOffsets[P]);
     out.sparseRows.resize(out.sparseOffsets[P]);
     out.sparseCols.resize(out.sparseOffsets[P]);
@@ -164,8 +168,9 @@ inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, u
                 std::copy(in.dense_cols + (uint64_t)in.block_offsets[q] * 16, in.dense_cols + (uint64_t)in.block_offsets[q + 1] * 16,
                           out.denseCols.begin() + b0 * 16);
                 std::copy(in.block_values + (uint64_t)in.block_offsets[q] * 256,
-                          in.block_values + (uint64_t)in.block_offsets[q + 1] * 256, out.blockValues.begin() + b0 * 256);
+                          in.block_values + (uint64_t)in.block_offsets[q + 1] * 256, out.blockValues.get() + b0 * 256);
             }
+            std::fill(out.blockValues.get() + (b0 + own) * 256, out.blockValues.get() + (b0 + own + take[q]) * 256, kNone);
             std::copy(newCols[q].begin(), newCols[q].begin() + (size_t)take[q] * 16, out.denseCols.begin() + (b0 + own) * 16);
             uint32_t at = out.sparseOffsets[q];
             for (uint32_t i = in.sparse_value_offsets[q]; i < in.sparse_value_offsets[q + 1]; ++i) {
@@ -183,7 +188,7 @@ inline bool promoteSparseBlocks(const bsmr_rphm_desc& in, uint32_t minAverage, u
     out.desc = in;
     out.desc.dense_cols = out.denseCols.data();
     out.desc.block_offsets = out.blockOffsets.data();
-    out.desc.block_values = out.blockValues.data();
+    out.desc.block_values = out.blockValues.get();
     out.desc.sparse_value_offsets = out.sparseOffsets.data();
     out.desc.sparse_values = out.sparseValues.data();
     out.desc.sparse_relative_rows = out.sparseRows.data();
