@@ -48,7 +48,9 @@ class TuneReport(C.Structure):
                 ("stream_us", C.c_float), ("grouped_us", C.c_float), ("tiles_us", C.c_float), ("shared_us", C.c_float),
                 ("chosen_b_only", C.c_int32), ("fp32_residue_us", C.c_float), ("b_only_us", C.c_float),
                 ("chosen_overlap", C.c_int32), ("one_stream_us", C.c_float), ("two_streams_us", C.c_float),
-                ("chosen_cvt_in_kernel", C.c_int32), ("convert_pass_us", C.c_float), ("fp32_dense_us", C.c_float)]
+                ("chosen_cvt_in_kernel", C.c_int32), ("convert_pass_us", C.c_float), ("fp32_dense_us", C.c_float),
+                ("sweep_us", C.c_float), ("lowp_call_us", C.c_float), ("sweep_fp32_call_us", C.c_float),
+                ("chosen_sweep_fp32", C.c_int32)]
 
 
 class PlanBuildMs(C.Structure):
@@ -74,11 +76,12 @@ class PlanOptions(C.Structure):
         "promote_head", "dense_group", "dense_blocks_per_item", "stream_waves", "output_mode", "force_tile32",
         "column_order", "dense_stream", "dense_batch", "tile_group", "tile_blocks_per_item", "tile_depth",
         "sparse_entries_per_item", "sparse_lowp", "sparse_lpe", "free_residue", "convert_in_kernel", "convert_sliced",
-        "b_only", "b_only_work_m", "overlap_streams", "mask_tiles", "pack_on_device")]
+        "b_only", "b_only_work_m", "overlap_streams", "mask_tiles", "pack_on_device", "sweep_panels", "sweep_strip_blocks",
+        "sweep_fp32", "sweep_waves", "sweep_per_cu")]
 
 
-ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED, ENGINE_TUNED = 0, 1, 2, 3
-ENGINE_NAMES = {0: "stream", 1: "tiles", 2: "shared"}
+ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED, ENGINE_TUNED, ENGINE_SWEEP = 0, 1, 2, 3, 4
+ENGINE_NAMES = {0: "stream", 1: "tiles", 2: "shared", 4: "sweep"}
 
 
 class ReorderingReport(C.Structure):
@@ -502,9 +505,10 @@ def plan_tune(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, mode=COMPUTE_F16
     r = TuneReport()
     _check(hip().bsmr_plan_tune(plan, K, A_ptr, B_ptr, P_ptr, mode, stream, C.byref(r)), "bsmr_plan_tune")
     out = {"chosen": ENGINE_NAMES[r.chosen_engine], "group": r.chosen_group, "blocks_per_item": r.chosen_blocks_per_item}
-    for name in ("stream_us", "grouped_us", "tiles_us", "shared_us", "fp32_residue_us", "b_only_us", "one_stream_us", "two_streams_us", "convert_pass_us", "fp32_dense_us"):
+    for name in ("stream_us", "grouped_us", "tiles_us", "shared_us", "fp32_residue_us", "b_only_us", "one_stream_us", "two_streams_us", "convert_pass_us", "fp32_dense_us", "sweep_us", "lowp_call_us", "sweep_fp32_call_us"):
         out[name] = round(getattr(r, name), 2)
     out["b_only"], out["overlap"], out["cvt_in_kernel"] = r.chosen_b_only, r.chosen_overlap, r.chosen_cvt_in_kernel
+    out["sweep_fp32"] = r.chosen_sweep_fp32
     return out
 
 

@@ -138,6 +138,8 @@ int bsmr_device_synchronize(int device);
 #define BSMR_ENGINE_STREAM  0  /* dense part: per-panel streaming kernels (denseStream / denseGroups), the default */
 #define BSMR_ENGINE_TILES   1  /* dense part: "tiles" format, H panels per wave-private B image (denseTiles)     */
 #define BSMR_ENGINE_SHARED  2  /* dense part: "tiles" format, B images shared by the 4 waves of a workgroup        */
+#define BSMR_ENGINE_SWEEP   4  /* dense part computed like a GEMM: row groups x strips of B in natural column order,
+                                  B streamed once by loader waves, no gather (denseSweep, csrc/sweep_kernels.hpp)  */
 #define BSMR_ENGINE_TUNED   3  /* the plan keeps what every engine needs; calls use the streaming engine until
                                   bsmr_plan_tune has timed the three for their (K, mode) and then the fastest          */
 typedef struct bsmr_plan_options {
@@ -184,6 +186,15 @@ typedef struct bsmr_plan_options {
                                        (csrc/pack_device.hpp; byte-identical to the host packer, which still does every
                                        layout but the default one): 1 = whenever possible, 0 = never,
                                        -1 = from 4096 dense blocks (default)                               [PACK_ON_DEVICE] */
+    /* device format of the dense part, sweep engine (fields added in round 3: older callers' struct_size leaves the defaults) */
+    int32_t  sweep_panels;          /* panels per consumer wave (a row group is 4 x this many panels): 0 = by K; 1, 2, 4
+                                                                                                              [SWEEP_PANELS] */
+    int32_t  sweep_strip_blocks;    /* 16-column blocks of B per work item: 0 = from the plan's shape; <= 63   [SWEEP_BLOCKS] */
+    int32_t  sweep_fp32;            /* sweep kernel on the caller's fp32 operands, rounded in registers (no conversion
+                                       pass): -1 = for K <= 128 (default), 0 = never, 1 = whenever K <= 128    [SWEEP_FP32] */
+    int32_t  sweep_waves;           /* consumer waves per workgroup: 0 = 4; 4, 8                                [SWEEP_WAVES] */
+    int32_t  sweep_per_cu;          /* workgroups per CU the LDS ring is sized for: 0 = 1; 1, 2 (2: four consumer waves only)
+                                                                                                              [SWEEP_PER_CU] */
 } bsmr_plan_options;
 int bsmr_plan_options_default(bsmr_plan_options *opt);
 /* defaults, then every BSMR_<NAME> variable that is set */
@@ -213,9 +224,11 @@ int bsmr_plan_build_times(const bsmr_plan *plan, bsmr_plan_build_ms *out);
  * Needs a plan created with dense_engine = BSMR_ENGINE_TUNED; P is overwritten with the (correct) result.  The
  * reference has no counterpart: it tunes (alpha, delta) per matrix by sweeping (src/sddmm.cu:62-118). */
 typedef struct bsmr_tune_report {
-    int32_t chosen_engine;            /* BSMR_ENGINE_STREAM / _TILES / _SHARED */
-    int32_t chosen_group;             /* panels per group of the winner (streaming engine: 1, or 4 = the grouped format) */
-    int32_t chosen_blocks_per_item;   /* shared-B engine: blocks per work item where that was part of the search, else 0 */
+    int32_t chosen_engine;            /* BSMR_ENGINE_STREAM / _TILES / _SHARED / _SWEEP */
+    int32_t chosen_group;             /* panels per group of the winner (streaming engine: 1, or 4 = the grouped format;
+                                         sweep engine: panels per consumer wave) */
+    int32_t chosen_blocks_per_item;   /* shared-B engine: blocks per work item where that was part of the search, else 0;
+                                         sweep engine: blocks per strip */
     /* best dense-kernel time per launch of each candidate family, microseconds; < 0: not measured (no such format,
      * the engine does not serve this K, or nothing to choose from) */
     float   stream_us, grouped_us, tiles_us, shared_us;
@@ -230,6 +243,11 @@ typedef struct bsmr_tune_report {
      * rounds them in registers (same results); -1 / < 0: does not apply */
     int32_t chosen_cvt_in_kernel;
     float   convert_pass_us, fp32_dense_us;
+    /* sweep engine (round 3; appended): best dense-kernel time on 16-bit operands (comparable with stream_us ...), and whole
+     * calls: the best 16-bit engine behind the conversion pass against the sweep kernel on the fp32 operands */
+    float   sweep_us;
+    float   lowp_call_us, sweep_fp32_call_us;
+    int32_t chosen_sweep_fp32;        /* 1: the chosen engine is the sweep kernel on fp32 operands */
 } bsmr_tune_report;
 int bsmr_plan_tune(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev, float *P_dev, int mode, void *stream,
                    bsmr_tune_report *report /* may be NULL */);

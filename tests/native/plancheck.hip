@@ -186,3 +186,81 @@ extern "C" int plancheck_tiles(const bsmr_rphm_desc* d, uint32_t H, uint32_t blo
     if (census.blocks == f.numBlocks && census.tiles != f.numTiles) return 18;
     return 0;
 }
+
+#include "sweep_format.hpp"
+
+// csrc/sweep_format.hpp read the way denseSweep reads it: every dense entry of the RPHM is listed exactly once, in
+// the (item, wave, block) list of its row group / panel / column block, with the slab slot of its accumulator cell.
+// out[0] items, [1] words, [2] groups, [3] strips, [4] most entries in one (wave, block) step, [5] bytes.
+extern "C" int plancheck_sweep(const bsmr_rphm_desc* d, uint32_t W, uint32_t PW, uint32_t stripBlocks, uint64_t* out) {
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    bsmr::HostDense hd;
+    int st = bsmr::collectDense(d, hd);
+    if (st != BSMR_OK) return 100 + st;
+    bsmr::SweepFormatHost f;
+    st = bsmr::packSweep(hd, W, PW, stripBlocks, f);
+    if (st != BSMR_OK) return 200 + st;
+    out[0] = f.items.size(); out[1] = hd.entries(); out[2] = f.numGroups; out[3] = f.numStrips;
+    out[4] = f.maxStepEntries; out[5] = f.bytes();
+    std::vector<uint32_t> wantRow(d->nnz, kNone), wantCol(d->nnz, kNone);
+    uint64_t denseEntries = 0;
+    for (uint32_t p = 0; p < d->num_row_panels; ++p)
+        for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b)
+            for (uint32_t i = 0; i < 256; ++i) {
+                const uint32_t v = d->block_values[b * 256 + i];
+                if (v == kNone) continue;
+                const size_t slot = (size_t)p * 16 + i / 16;
+                wantRow[v] = slot < d->num_nonzero_rows ? d->reordered_rows[slot] : kNone;
+                wantCol[v] = d->dense_cols[b * 16 + i % 16];
+                ++denseEntries;
+            }
+    if (hd.entries() != denseEntries) return 1;
+    const uint32_t GP = W * PW, NCB = (d->N + 15) / 16;
+    if (f.items.size() != (size_t)f.numGroups * f.numStrips) return 2;
+    if (f.panelRows.size() != (size_t)f.numGroups * GP * 16) return 3;
+    std::vector<uint8_t> seen(d->nnz, 0);
+    std::vector<uint32_t> blockCover(NCB, 0);
+    uint64_t expectStart = 0;
+    for (size_t it = 0; it < f.items.size(); ++it) {
+        const bsmr::SweepItem& item = f.items[it];
+        if (item.group >= f.numGroups || item.numBlocks == 0 || item.numBlocks > bsmr::kSweepMaxBlocks ||
+            item.firstBlock + item.numBlocks > NCB)
+            return 4;
+        if (it / f.numGroups != item.firstBlock / stripBlocks || it % f.numGroups != item.group) return 5;   // strip-major
+        if (item.group == 0)
+            for (uint32_t b = 0; b < item.numBlocks; ++b) ++blockCover[item.firstBlock + b];
+        for (uint32_t w = 0; w < W; ++w) {
+            const uint32_t* starts = &f.starts[(size_t)item.startsBase + (size_t)w * (item.numBlocks + 1)];
+            if (starts[0] != expectStart) return 6;    // the lists follow each other without gaps
+            for (uint32_t b = 0; b < item.numBlocks; ++b) {
+                if (starts[b + 1] < starts[b] || starts[b + 1] - starts[b] > ((f.maxStepEntries + 3u) & ~3u) || starts[b] % 4) return 7;
+                for (uint32_t e = starts[b]; e < starts[b + 1]; ++e) {
+                    const uint32_t word = f.words[e], slot = word & 1023u, rw = (word >> 10) & 63u, off = word >> 16;
+                    if (word == bsmr::kSweepNoEntry) {   // padding to a multiple of 4 words, at the end of the list only
+                        if (starts[b + 1] - e > 3) return 17;
+                        continue;
+                    }
+                    if (e + 1 < starts[b + 1] && f.words[e + 1] != bsmr::kSweepNoEntry && e > starts[b] && f.words[e - 1] == bsmr::kSweepNoEntry) return 18;
+                    if (rw >= 16 * PW) return 8;
+                    const uint32_t j = rw / 16, r = rw % 16;
+                    if (slot >= PW * 256 || slot / 256 != j) return 9;
+                    const uint32_t reg = slot & 3u, lane = (slot >> 2) & 63u;
+                    if (reg != (r & 3u) || lane / 16 != r / 4) return 10;   // accumulator layout: lane = 16 (r / 4) + c, register r % 4
+                    const uint32_t c = lane & 15u;
+                    const uint32_t idx = f.rowStart[(it * W + w) * (16 * PW) + rw] + off;
+                    if (idx >= d->nnz || seen[idx]++) return 11;
+                    if (f.panelRows[((size_t)item.group * GP + w * PW + j) * 16 + r] != wantRow[idx]) return 12;
+                    if ((item.firstBlock + b) * 16 + c != wantCol[idx]) return 13;
+                }
+            }
+            expectStart = starts[item.numBlocks];
+        }
+        if (expectStart - f.starts[item.startsBase] > f.maxItemWords) return 19;
+    }
+    if (f.words.size() < expectStart + bsmr::kSweepWordSlack) return 14;   // the loaders move an item's words in whole pseudo-images
+    for (uint32_t b = 0; b < NCB; ++b)
+        if (blockCover[b] != 1) return 15;
+    for (uint32_t v = 0; v < d->nnz; ++v)
+        if ((wantRow[v] != kNone) != (seen[v] != 0)) return 16;
+    return 0;
+}

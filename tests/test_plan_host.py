@@ -158,3 +158,73 @@ def test_promotion_with_repeated_entries(plancheck):
     assert rc == 0, r
     assert r["promoted"] == 1 and r["packed_dense"] + r["packed_residue"] == r["nnz"]
     assert r["residue"] == 3 * rows                               # the second copies
+
+
+@pytest.fixture(scope="module")
+def sweepcheck(engine):
+    lib = C.CDLL(str(REPO / "tests" / "native" / "libplancheck.so"))
+    lib.plancheck_sweep.restype = C.c_int
+    lib.plancheck_sweep.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+
+    def run(rows, cols, ro, ci, alpha, delta, panels_per_wave, strip_blocks, waves=4):
+        csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+        pipe = engine.Pipeline(csr, alpha=alpha, delta=delta, device=-1)
+        arrays = pipe.arrays()
+        keep = {k: np.ascontiguousarray(arrays[k], dtype=np.uint32) for k in
+                ("reorderedRows", "denseCols", "blockOffsets", "blockValues", "sparseValueOffsets",
+                 "sparseValues", "sparseRelativeRows", "sparseColIndices")}
+        d = engine.RphmDesc()
+        d.M, d.N, d.nnz = rows, cols, csr.nnz
+        d.num_nonzero_rows = keep["reorderedRows"].size
+        d.num_row_panels = keep["blockOffsets"].size - 1
+        cast = lambda a: a.ctypes.data_as(engine.u32p)
+        d.reordered_rows, d.dense_cols = cast(keep["reorderedRows"]), cast(keep["denseCols"])
+        d.block_offsets, d.block_values = cast(keep["blockOffsets"]), cast(keep["blockValues"])
+        d.sparse_value_offsets, d.sparse_values = cast(keep["sparseValueOffsets"]), cast(keep["sparseValues"])
+        d.sparse_relative_rows, d.sparse_col_indices = cast(keep["sparseRelativeRows"]), cast(keep["sparseColIndices"])
+        out = (C.c_uint64 * 6)()
+        rc = lib.plancheck_sweep(C.byref(d), waves, panels_per_wave, strip_blocks, out)
+        res = dict(zip(("items", "entries", "groups", "strips", "max_step_entries", "bytes"), (int(v) for v in out)))
+        res["rphm_dense"] = int(csr.nnz - keep["sparseValues"].size)
+        return rc, res
+    return run
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("panels_per_wave", [1, 2, 4])
+@pytest.mark.parametrize("strip_blocks", [1, 7, 63])
+def test_sweep_format_lists_every_dense_entry_once(sweepcheck, panels_per_wave, strip_blocks, waves):
+    """csrc/sweep_format.hpp, read the way denseSweep reads it: each dense entry of the RPHM once, in the list of its
+    (row group, strip, wave, block), with the accumulator cell of its (row, column) - all-dense and hybrid plans, a
+    ragged last row group (21 panels) and a ragged last column block (1500 = 93 * 16 + 12)."""
+    rows, cols, ro, ci = synth.nips_like(rows=330, cols=1500, nnz=42000, seed=3)
+    for delta in (0.0, 0.1):
+        rc, r = sweepcheck(rows, cols, ro, ci, 0.3, delta, panels_per_wave, strip_blocks, waves)
+        assert rc == 0, f"invariant {rc} violated: {r}"
+        assert r["entries"] == r["rphm_dense"] > 0
+        assert r["groups"] == -(-21 // (waves * panels_per_wave)) and r["strips"] == -(-94 // strip_blocks)
+        assert r["items"] == r["groups"] * r["strips"]
+
+
+def test_sweep_format_takes_unsorted_rows_and_full_tiles(sweepcheck):
+    """CSR rows in file order (the reference's loader keeps it): the entry words carry explicit offsets, so the format
+    does not need sorted rows; a full matrix fills every step with 256 entries per panel."""
+    rng = np.random.default_rng(5)
+    rows, cols, ro, ci = synth.random_pattern(150, 220, 5000, seed=11, empty_rows=9)
+    ci = ci.copy()
+    for i in range(rows):
+        rng.shuffle(ci[ro[i]:ro[i + 1]])
+    rc, r = sweepcheck(rows, cols, ro, ci, 0.3, 0.0, 2, 5)
+    assert rc == 0 and r["entries"] == ci.size, (rc, r)
+    rows, cols = 128, 64
+    ro = np.arange(rows + 1, dtype=np.uint32) * cols
+    ci = np.tile(np.arange(cols, dtype=np.uint32), rows)
+    rc, r = sweepcheck(rows, cols, ro, ci, 0.3, 0.0, 2, 3)
+    assert rc == 0 and r["max_step_entries"] == 512, (rc, r)
+
+
+def test_sweep_format_rejects_shapes_it_cannot_hold(sweepcheck):
+    rows, cols, ro, ci = synth.random_pattern(40, 60, 500, seed=2)
+    assert sweepcheck(rows, cols, ro, ci, 0.3, 0.0, 3, 4)[0] == 201      # panels per wave: 1, 2 or 4
+    assert sweepcheck(rows, cols, ro, ci, 0.3, 0.0, 2, 64)[0] == 201     # at most 63 blocks per strip
+    assert sweepcheck(rows, cols, ro, ci, 0.3, 0.0, 2, 8, waves=6)[0] == 201   # 4 or 8 consumer waves
