@@ -147,6 +147,7 @@ struct bsmr_plan {
         int bOnly = -1;     // all-sparse plans: 1 = convert B alone and read 16-bit operands, 0 = fp32 residue, -1 = the rule
         int overlap = -1;   // hybrid plans: 1 = residue kernel on the side stream, 0 = one stream, -1 = as the plan was built
         int cvt = -1;       // K = 32 / 64: 1 = fp32 operands rounded inside the dense kernel (no conversion pass), 0 = pass, -1 = the rule
+        int waves = 0;      // sweep engine: consumer waves (0 = the option / rule); its panels per wave are `group`, its strip `blocksPerItem`
     };
     std::map<uint64_t, Tuned> tuned;   // ... from what bsmr_plan_tune measured for (K << 8 | mode); untuned calls stream
     int tileGroupNow = 0, tileBlocksNow = 0;   // tuned group size / blocks per item of the call being prepared
@@ -878,7 +879,8 @@ inline uint32_t sweepMinPanels(uint32_t K) { return K >= 512 ? 1u : 2u; }
 inline bool sweepFp32(const bsmr_plan* p, uint32_t K) {
     if (K > 128) return false;
     if (p->cvtNow >= 0) return p->cvtNow == 1;
-    return p->opt.sweep_fp32 != 0;
+    // (the residue of such a call runs its fp32 kernel: by rule only plans without one; bsmr_plan_tune measures both)
+    return p->opt.sweep_fp32 > 0 || (p->opt.sweep_fp32 < 0 && p->numSparseItems == 0);
 }
 // blocks per strip for `wgPerCu` workgroups per CU: the items of one launch should fill the chip in whole rounds
 inline uint32_t sweepStripBlocks(const bsmr_plan* p, uint32_t W, uint32_t PW, uint32_t wgPerCu) {
@@ -956,7 +958,8 @@ int ensureSweep(bsmr_plan* p, uint32_t K) {
 template <int KS, int PW, int MODE, bool SRC32, int W, int PERCU>
 int launchSweepT(const SweepFormatDev& w, int device, uint32_t N, const void* A, const void* B, float* P, const Queue& s) {
     // loader waves: an LDS-DMA instruction moves 1 KiB and costs its wave ~60-200 cycles of issue; 8 of them when an image is 8 KiB or more
-    constexpr int NL = (SRC32 ? 2 * KS : KS) >= 8 ? 8 : 4;
+    // (a workgroup of 8 + 4 waves leaves 170 registers per lane: only where the A fragments take 64 of them or fewer)
+    constexpr int NL = (SRC32 ? 2 * KS : KS) >= 8 && PW * KS <= 16 ? 8 : 4;
     constexpr int NBB = 2;                              // images per workgroup barrier
     auto kernel = bsmr::denseSweep<KS, PW, MODE, SRC32, W, NL, PERCU, NBB>;
     const size_t lds = bsmr::sweepLdsBytes(KS, PW, SRC32, W, PERCU, NBB);
@@ -1276,6 +1279,7 @@ int prepareDense(bsmr_plan* p, uint32_t K, int mode) {
         p->tileBlocksNow = p->useTiles ? choice.blocksPerItem : 0;
         p->sweepPanelsNow = p->useSweep ? choice.group : 0;
         p->sweepBlocksNow = p->useSweep ? choice.blocksPerItem : 0;
+        p->sweepWavesNow = p->useSweep ? choice.waves : 0;
         p->formatNow = choice.format;
         p->bOnlyNow = choice.bOnly;
         p->overlapNow = choice.overlap;
@@ -1572,10 +1576,12 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         bsmr_rphm_desc folded;
         std::vector<uint32_t> fBlockOffsets, fSparseOffsets, fValues, fRows, fCols;
         uint64_t foldedEntries = 0;
-        bool offsetsOk = true;  // malformed offsets are left to packPlan's validation
+        // offsets that do not ascend are rejected here: the device packer and the residue packer index with them unchecked
+        bool offsetsOk = true;
         for (uint32_t q = 0; q < P && offsetsOk; ++q)
             offsetsOk = d->block_offsets[q] <= d->block_offsets[q + 1] &&
                         d->sparse_value_offsets[q] <= d->sparse_value_offsets[q + 1];
+        if (!offsetsOk || d->block_offsets[0] != 0 || d->sparse_value_offsets[0] != 0 || numSparse > d->nnz) return BSMR_ERR_BAD_PLAN;
         // A panel whose residue averages >= 16 entries per 16-column block is cheaper on the MFMA path
         // (plan_promote.hpp; mycielskian15 alpha = delta = 0.3, K = 128: 66.8 -> 48.1 us).  A plan without a
         // dense part only changes when a million entries move: the first dense block brings the conversion pass
@@ -2079,6 +2085,8 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
     r.fp32_residue_us = r.b_only_us = r.one_stream_us = r.two_streams_us = -1.f;
     r.chosen_cvt_in_kernel = -1;
     r.convert_pass_us = r.fp32_dense_us = -1.f;
+    r.sweep_us = r.lowp_call_us = r.sweep_fp32_call_us = -1.f;
+    r.chosen_sweep_fp32 = 0;
     BSMR_HIP(hipSetDevice(plan->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t key = ((uint64_t)K << 8) | (uint32_t)mode;
@@ -2097,10 +2105,18 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
     auto timeChoice = [&](const bsmr_plan::Tuned& c, int which, float& us) -> int {
         us = -1.f;
         plan->tuned[key] = c;
-        if (const int pst = prepareDense(plan, K, mode)) return c.engine == BSMR_ENGINE_STREAM ? pst : BSMR_OK;
+        // (a candidate that cannot be prepared or launched - an engine's format does not fit, say - simply cannot run:
+        // us stays < 0 and the search goes on; only what the rules themselves launch fails the tune)
+        const bool isRule = c.engine == BSMR_ENGINE_STREAM && c.format <= 0 && c.cvt <= 0;
+        if (const int pst = prepareDense(plan, K, mode)) return isRule ? pst : BSMR_OK;
+        if (c.engine == BSMR_ENGINE_SWEEP && !sweepEngine(plan)) return BSMR_OK;   // (this shape cannot be packed)
         int rc = BSMR_OK;
         if (needsWorkspace(plan, mode, K) && (rc = reserve(plan, K)) != BSMR_OK) return rc;
         for (int i = 0; i < 3 && rc == BSMR_OK; ++i) rc = runPieces(plan, K, A, B, P, mode, s, which);
+        if (rc != BSMR_OK && !isRule) {
+            (void)hipStreamSynchronize(s);
+            return BSMR_OK;
+        }
         hipError_t e = hipEventRecord(e0, s);
         for (int i = 0; i < 10 && rc == BSMR_OK; ++i) rc = runPieces(plan, K, A, B, P, mode, s, which);
         if (e == hipSuccess) e = hipEventRecord(e1, s);
@@ -2124,6 +2140,16 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
             for (int h = 4; h <= (int)std::min<uint32_t>(8u, sharedMaxH); h *= 2)
                 for (const int blocks : {8, 16, 32}) candidates.push_back({BSMR_ENGINE_SHARED, h, blocks});
         }
+        // the sweep engine on the 16-bit copies (its strip from the plan's shape): four fat or eight lean consumer waves
+        if (sweepApplies(plan) && sweepServesK(K)) {
+            bsmr_plan::Tuned c{BSMR_ENGINE_SWEEP, (int)sweepMaxPanels(K), 0};
+            c.cvt = K <= 128 ? 0 : -1;   // (the 16-bit copies here; the kernel on fp32 operands is step 5's whole-call comparison)
+            c.waves = 4;
+            candidates.push_back(c);
+            c.group = (int)sweepMinPanels(K);
+            c.waves = 8;
+            candidates.push_back(c);
+        }
         if (candidates.size() > 1) {
             if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;
             st = runPieces(plan, K, A, B, P, mode, s, 1);   // the converted operands every candidate reads
@@ -2133,6 +2159,7 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
                 st = timeChoice(candidates[c], 2, us);
                 if (st != BSMR_OK || us < 0.f) continue;
                 float& slot = candidates[c].engine == BSMR_ENGINE_TILES    ? r.tiles_us
+                              : candidates[c].engine == BSMR_ENGINE_SWEEP  ? r.sweep_us
                               : candidates[c].engine == BSMR_ENGINE_SHARED ? r.shared_us
                               : candidates[c].format == 1                  ? r.grouped_us
                                                                            : r.stream_us;
@@ -2169,7 +2196,7 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
             best.overlap = plan->overlap ? (r.one_stream_us < r.two_streams_us * kTuneMargin ? 0 : 1)
                                          : (r.two_streams_us < r.one_stream_us * kTuneMargin ? 1 : 0);
     }
-    // 4. K = 32 / 64: conversion pass + 16-bit kernels against the streaming kernel that reads the fp32 operands itself
+    // 4. K = 32 / 64 / 128: conversion pass + 16-bit kernels against the streaming kernel that reads the fp32 operands itself
     //    (then the residue, if any, runs its fp32 kernel): whole call
     if (st == BSMR_OK && lowp && plan->fmt[0].numItems && streamCvtServes(plan->fmt[0], K) && plan->useStream &&
         !(plan->sparseLowp && plan->numSparseEntries > 10ull * ((uint64_t)plan->M + plan->N))) {
@@ -2190,6 +2217,31 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
             else best.cvt = 0;
         }
     }
+    // 5. K <= 128: the best of the above as a whole call against the sweep kernel on the caller's fp32 operands (no
+    //    conversion pass, one launch; a residue then runs its fp32 kernel)
+    if (st == BSMR_OK && lowp && K <= 128 && plan->fmt[0].numItems && !plan->convertInKernel && sweepApplies(plan) && sweepServesK(K)) {
+        st = timeChoice(best, 7, r.lowp_call_us);
+        bsmr_plan::Tuned f = best;
+        f.engine = BSMR_ENGINE_SWEEP;
+        f.format = -1;
+        f.blocksPerItem = 0;
+        f.cvt = 1;
+        bsmr_plan::Tuned bestF = f;
+        for (int variant = 0; variant < 2 && st == BSMR_OK; ++variant) {
+            f.waves = variant ? 8 : 4;
+            f.group = (int)(variant ? sweepMinPanels(K) : sweepMaxPanels(K));
+            float us = -1.f;
+            st = timeChoice(f, 7, us);
+            if (st == BSMR_OK && us >= 0.f && (r.sweep_fp32_call_us < 0.f || us < r.sweep_fp32_call_us)) {
+                r.sweep_fp32_call_us = us;
+                bestF = f;
+            }
+        }
+        if (st == BSMR_OK && r.lowp_call_us >= 0.f && r.sweep_fp32_call_us >= 0.f && r.sweep_fp32_call_us < r.lowp_call_us * kTuneMargin) {
+            best = bestF;
+            r.chosen_sweep_fp32 = 1;
+        }
+    }
     if (st != BSMR_OK) {
         plan->tuned.erase(key);
         return st;
@@ -2203,6 +2255,7 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
     r.chosen_overlap = best.overlap;
     // leave a complete result in P and the chosen engine's format in place
     if ((st = prepareDense(plan, K, mode)) != BSMR_OK) return st;
+    if (best.engine == BSMR_ENGINE_SWEEP && sweepEngine(plan)) r.chosen_blocks_per_item = (int)plan->sweeps[(size_t)plan->sweepNow].stripBlocks;
     if (needsWorkspace(plan, mode, K) && (st = reserve(plan, K)) != BSMR_OK) return st;
     st = runPieces(plan, K, A, B, P, mode, s, 7);
     if (st == BSMR_OK && report) *report = r;

@@ -145,16 +145,18 @@ struct bsmr_colreorder {
     uint32_t *denseCols = nullptr, *sparseCols = nullptr, *blockValues = nullptr, *sparseValues = nullptr,
              *sparseRows = nullptr, *sparseColIdx = nullptr;
     std::vector<uint32_t> denseColOffsets, sparseColOffsets, sparseValueOffsets, blockOffsets;   // host (small)
+    // (the result owns its device arrays: an early return of bsmr_col_reorder drops a half-built one through unique_ptr)
+    ~bsmr_colreorder() {
+        if (hipSetDevice(device) != hipSuccess) (void)hipGetLastError();
+        void* ptrs[] = {denseCols, sparseCols, blockValues, sparseValues, sparseRows, sparseColIdx};
+        for (void* q : ptrs)
+            if (q) (void)hipFree(q);
+    }
 };
 
 extern "C" {
 
 int bsmr_col_reorder_free(bsmr_colreorder* h) {
-    if (!h) return BSMR_OK;
-    if (hipSetDevice(h->device) != hipSuccess) (void)hipGetLastError();
-    void* ptrs[] = {h->denseCols, h->sparseCols, h->blockValues, h->sparseValues, h->sparseRows, h->sparseColIdx};
-    for (void* q : ptrs)
-        if (q) (void)hipFree(q);
     delete h;
     return BSMR_OK;
 }
@@ -177,6 +179,7 @@ int bsmr_col_reorder(bsmr_colreorder** out, int device, uint32_t rows, uint32_t 
             outStart[q + 1] = outStart[q] + (row_offsets[reordered_rows[q] + 1] - row_offsets[reordered_rows[q]]);
         }
         const uint32_t n = outStart[num_reordered];
+        if (n > 0x7FFFFFFFu) return BSMR_ERR_INVALID_ARG;   // (hipCUB counts in int: the caller keeps the host implementation)
         std::unique_ptr<bsmr_colreorder> h(new bsmr_colreorder);
         h->device = device;
         h->numPanels = P;
@@ -188,13 +191,16 @@ int bsmr_col_reorder(bsmr_colreorder** out, int device, uint32_t rows, uint32_t 
             *out = h.release();
             return BSMR_OK;
         }
-        hipEvent_t ev0, ev1;
-        BSMR_HIP(hipEventCreate(&ev0));
-        BSMR_HIP(hipEventCreate(&ev1));
         struct EventGuard {
-            hipEvent_t a, b;
-            ~EventGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
-        } guard{ev0, ev1};
+            hipEvent_t a = nullptr, b = nullptr;
+            ~EventGuard() {
+                if (a) (void)hipEventDestroy(a);
+                if (b) (void)hipEventDestroy(b);
+            }
+        } guard;
+        BSMR_HIP(hipEventCreate(&guard.a));
+        BSMR_HIP(hipEventCreate(&guard.b));
+        const hipEvent_t ev0 = guard.a, ev1 = guard.b;
         hipStream_t s = nullptr;
         BSMR_HIP(hipEventRecord(ev0, s));
         DeviceBuffers dev;   // scratch, freed on return

@@ -37,6 +37,8 @@
 #include <thread>
 #include <vector>
 
+#include <exception>
+
 #include "bsmr_hip.h"
 #include "sddmm_kernels.hpp"
 
@@ -72,13 +74,25 @@ inline void parallelChunks(size_t n, size_t minPerWorker, F fn) {
         fn((size_t)0, n, (size_t)0);
         return;
     }
+    // what a worker throws (std::bad_alloc from a vector, a length_error) is carried to the calling thread, which
+    // has the C ABI's catch around it; left in the worker it would end the process (std::terminate)
     std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> failed(workers);
     const size_t per = (n + workers - 1) / workers;
     for (size_t w = 0; w < workers; ++w) {
         const size_t b = std::min(n, w * per), e = std::min(n, b + per);
-        if (b < e) pool.emplace_back([=, &fn]() { fn(b, e, w); });
+        if (b < e)
+            pool.emplace_back([=, &fn, &failed]() {
+                try {
+                    fn(b, e, w);
+                } catch (...) {
+                    failed[w] = std::current_exception();
+                }
+            });
     }
     for (std::thread& t : pool) t.join();
+    for (const std::exception_ptr& f : failed)
+        if (f) std::rethrow_exception(f);
 }
 
 struct PackOptions {

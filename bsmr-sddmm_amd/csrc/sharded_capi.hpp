@@ -3,9 +3,12 @@
 // Row panels are independent: the caller cuts the rows of S into contiguous ranges, builds the RPHM of
 // every range (host pipeline), and hands the ranges' RPHM arrays over.  Shard i lives on devices[i]: its plan, its rows
 // of A, a replica of B, its part of P.  A step launches bsmr_sddmm on every device (asynchronous launches from the
-// calling thread, one stream per device), then ONE gather-v of the compact fp32 outputs to devices[0] - RCCL send / recv
-// inside one group, created once per sharded object (ncclCommInitAll over the device list); ranges are contiguous in
-// S's row order, so the root's P is the concatenation of the shards' outputs and no permutation pass is needed.
+// calling thread, one stream per shard), then ONE gather-v of the compact fp32 outputs to devices[0] - RCCL send / recv
+// inside one group, created once per sharded object (ncclCommInitAll over the DISTINCT devices of the list); ranges are
+// contiguous in S's row order, so the root's P is the concatenation of the shards' outputs and no permutation pass is
+// needed.  A device may appear more than once in the list (several shards on one GPU: a rehearsal of the N-shard
+// arithmetic on a one-GPU box, or more shards than GPUs): a shard on the root's device hands its part over with a
+// device-to-device copy, RCCL only moves what crosses devices.
 // Included at the end of bsmr_capi.hip (one translation unit).
 #pragma once
 
@@ -55,7 +58,9 @@ struct bsmr_sharded {
     std::vector<uint32_t> rowBegin;      // [n+1] global row of every shard's first row
     std::vector<uint64_t> entryBegin;    // [n+1] offset of every shard's entries in P
     uint32_t M = 0, N = 0;
-    std::vector<ncclComm_t> comms;       // one per device (single-process communicator clique), empty for n = 1
+    std::vector<int> uniqueDevices;      // the distinct devices, root first; rankOf[i] = index of devices[i] in it
+    std::vector<int> rankOf;
+    std::vector<ncclComm_t> comms;       // one per distinct device (single-process communicator clique), empty for one device
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> start, stop;
     // device buffers of the last K served
@@ -87,19 +92,51 @@ void freeShardedBuffers(bsmr_sharded* s) {
         }                                                                      \
     } while (0)
 
-// the gather-v of one step: peers send their part, the root receives each into its slot
+// the calling thread's current device is the caller's business (a process that also hosts PyTorch relies on it)
+struct DeviceRestore {
+    int saved = -1;
+    DeviceRestore() {
+        if (hipGetDevice(&saved) != hipSuccess) {
+            (void)hipGetLastError();
+            saved = -1;
+        }
+    }
+    ~DeviceRestore() {
+        if (saved >= 0 && hipSetDevice(saved) != hipSuccess) (void)hipGetLastError();
+    }
+};
+
+// the gather-v of one step: peers hand their part to the root, which receives each into its slot
 int shardedGather(bsmr_sharded* s) {
     const size_t n = s->devices.size();
     if (n == 1) return BSMR_OK;
-    BSMR_NCCL(rccl().groupStart());
+    // shards on the root's device: a device-to-device copy on the shard's own stream (behind its SDDMM)
     for (size_t i = 1; i < n; ++i) {
         const uint64_t count = s->entryBegin[i + 1] - s->entryBegin[i];
-        if (!count) continue;
-        BSMR_NCCL(rccl().recv(s->P[0] + s->entryBegin[i], count, ncclFloat, (int)i, s->comms[0], s->streams[0]));
-        BSMR_NCCL(rccl().send(s->P[i], count, ncclFloat, 0, s->comms[i], s->streams[i]));
+        if (!count || s->rankOf[i] != 0) continue;
+        BSMR_HIP(hipSetDevice(s->devices[i]));
+        BSMR_HIP(hipMemcpyAsync(s->P[0] + s->entryBegin[i], s->P[i], count * 4, hipMemcpyDeviceToDevice, s->streams[i]));
     }
-    BSMR_NCCL(rccl().groupEnd());
-    return BSMR_OK;
+    if (s->comms.empty()) return BSMR_OK;
+    // the rest crosses devices: one RCCL group; an error inside it still closes the group
+    int status = BSMR_OK;
+    BSMR_NCCL(rccl().groupStart());
+    for (size_t i = 1; i < n && status == BSMR_OK; ++i) {
+        const uint64_t count = s->entryBegin[i + 1] - s->entryBegin[i];
+        if (!count || s->rankOf[i] == 0) continue;
+        ncclResult_t r = rccl().recv(s->P[0] + s->entryBegin[i], count, ncclFloat, s->rankOf[i], s->comms[0], s->streams[0]);
+        if (r == ncclSuccess) r = rccl().send(s->P[i], count, ncclFloat, 0, s->comms[(size_t)s->rankOf[i]], s->streams[i]);
+        if (r != ncclSuccess) {
+            g_lastHipError = std::string("ncclSend / ncclRecv: ") + rccl().errorString(r);
+            status = BSMR_ERR_HIP;
+        }
+    }
+    const ncclResult_t e = rccl().groupEnd();
+    if (e != ncclSuccess && status == BSMR_OK) {
+        g_lastHipError = std::string("ncclGroupEnd: ") + rccl().errorString(e);
+        status = BSMR_ERR_HIP;
+    }
+    return status;
 }
 
 }  // namespace
@@ -108,10 +145,14 @@ extern "C" {
 
 int bsmr_sharded_destroy(bsmr_sharded* s) {
     if (!s) return BSMR_OK;
+    DeviceRestore restore;
     freeShardedBuffers(s);
+    for (size_t u = 0; u < s->comms.size(); ++u) {
+        if (hipSetDevice(s->uniqueDevices[u]) != hipSuccess) (void)hipGetLastError();
+        if (s->comms[u]) (void)rccl().commDestroy(s->comms[u]);
+    }
     for (size_t i = 0; i < s->devices.size(); ++i) {
         if (hipSetDevice(s->devices[i]) != hipSuccess) (void)hipGetLastError();
-        if (i < s->comms.size() && s->comms[i]) (void)rccl().commDestroy(s->comms[i]);
         if (i < s->streams.size() && s->streams[i]) (void)hipStreamDestroy(s->streams[i]);
         if (i < s->start.size() && s->start[i]) (void)hipEventDestroy(s->start[i]);
         if (i < s->stop.size() && s->stop[i]) (void)hipEventDestroy(s->stop[i]);
@@ -130,12 +171,17 @@ int bsmr_sharded_create(bsmr_sharded** out, const int* devices, uint32_t num_dev
         if (!shard_descs[i] || row_begin[i + 1] < row_begin[i] || shard_descs[i]->M != row_begin[i + 1] - row_begin[i] ||
             shard_descs[i]->N != shard_descs[0]->N)
             return BSMR_ERR_INVALID_ARG;
-        for (uint32_t j = 0; j < i; ++j)
-            if (devices[j] == devices[i]) return BSMR_ERR_INVALID_ARG;   // one shard per device
     }
+    DeviceRestore restore;
     bsmr_sharded* s = new (std::nothrow) bsmr_sharded;
     if (!s) return BSMR_ERR_OOM;
     s->devices.assign(devices, devices + num_devices);
+    for (uint32_t i = 0; i < num_devices; ++i) {   // (a device may serve several shards: the distinct ones, root first)
+        size_t u = 0;
+        while (u < s->uniqueDevices.size() && s->uniqueDevices[u] != devices[i]) ++u;
+        if (u == s->uniqueDevices.size()) s->uniqueDevices.push_back(devices[i]);
+        s->rankOf.push_back((int)u);
+    }
     s->rowBegin.assign(row_begin, row_begin + num_devices + 1);
     s->M = row_begin[num_devices] - row_begin[0];
     s->N = shard_descs[0]->N;
@@ -147,19 +193,25 @@ int bsmr_sharded_create(bsmr_sharded** out, const int* devices, uint32_t num_dev
     int st = BSMR_OK;
     for (uint32_t i = 0; i < num_devices && st == BSMR_OK; ++i) {
         s->entryBegin[i + 1] = s->entryBegin[i] + shard_descs[i]->nnz;
-        st = bsmr_plan_create_ex(&s->plans[i], devices[i], shard_descs[i], options);
+        // (a row range without rows - more shards than non-empty row panels - has no plan and takes no part in a step)
+        if (shard_descs[i]->M != 0 && shard_descs[i]->nnz != 0) st = bsmr_plan_create_ex(&s->plans[i], devices[i], shard_descs[i], options);
         if (st != BSMR_OK) break;
+        if (hipSetDevice(devices[i]) != hipSuccess) {
+            (void)hipGetLastError();
+            st = BSMR_ERR_NO_DEVICE;
+            break;
+        }
         if (!hipOk(hipStreamCreateWithFlags(&s->streams[i], hipStreamNonBlocking), "hipStreamCreate") ||
             !hipOk(hipEventCreate(&s->start[i]), "hipEventCreate") || !hipOk(hipEventCreate(&s->stop[i]), "hipEventCreate"))
             st = BSMR_ERR_HIP;
     }
-    if (st == BSMR_OK && num_devices > 1) {
+    if (st == BSMR_OK && s->uniqueDevices.size() > 1) {
         if (!rccl().ok()) {
             g_lastHipError = "librccl.so.1 could not be loaded (needed for more than one device)";
             st = BSMR_ERR_HIP;
         } else {
-            s->comms.assign(num_devices, nullptr);
-            const ncclResult_t r = rccl().commInitAll(s->comms.data(), (int)num_devices, s->devices.data());
+            s->comms.assign(s->uniqueDevices.size(), nullptr);
+            const ncclResult_t r = rccl().commInitAll(s->comms.data(), (int)s->uniqueDevices.size(), s->uniqueDevices.data());
             if (r != ncclSuccess) {
                 g_lastHipError = std::string("ncclCommInitAll: ") + rccl().errorString(r);
                 st = BSMR_ERR_HIP;
@@ -187,6 +239,7 @@ int bsmr_sharded_sddmm_host(bsmr_sharded* s, uint32_t K, const float* A_host, co
     if (!s || !A_host || !B_host || !P_host) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     if (iters <= 0) iters = 1;
+    DeviceRestore restore;
     const size_t n = s->devices.size();
     const uint64_t nnz = s->entryBegin.back();
     // operands: shard i's rows of A, all of B, its part of P (the root holds the whole P)
@@ -203,7 +256,7 @@ int bsmr_sharded_sddmm_host(bsmr_sharded* s, uint32_t K, const float* A_host, co
                 !hipOk(hipMalloc(reinterpret_cast<void**>(&s->B[i]), std::max<size_t>((size_t)s->N * K * 4, 16)), "hipMalloc(B replica)") ||
                 !hipOk(hipMalloc(reinterpret_cast<void**>(&s->P[i]), std::max<size_t>(part * 4, 16)), "hipMalloc(P shard)"))
                 return BSMR_ERR_OOM;
-            int st = bsmr_plan_reserve(s->plans[i], K);
+            int st = s->plans[i] ? bsmr_plan_reserve(s->plans[i], K) : BSMR_OK;
             if (st != BSMR_OK) return st;
         }
         s->K = K;
@@ -221,6 +274,7 @@ int bsmr_sharded_sddmm_host(bsmr_sharded* s, uint32_t K, const float* A_host, co
     auto step = [&]() -> int {   // every device's SDDMM, then the gather
         for (size_t i = 0; i < n; ++i) {
             BSMR_HIP(hipSetDevice(s->devices[i]));
+            if (!s->plans[i]) continue;
             float* dst = i == 0 ? s->P[0] + s->entryBegin[0] : s->P[i];
             const int st = bsmr_sddmm(s->plans[i], K, s->A[i], s->B[i], dst, mode, s->streams[i]);
             if (st != BSMR_OK) return st;

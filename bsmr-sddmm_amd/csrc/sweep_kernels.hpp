@@ -6,12 +6,15 @@
 //
 // Work item = (row group of 16 * W * PW reordered rows) x (strip of consecutive 16-column blocks of B), format
 // csrc/sweep_format.hpp.  A workgroup is W CONSUMER waves and NL LOADER waves:
-//   * the loader waves stream a sequence of images through an LDS ring by LDS-DMA: first the item's entry words
-//     (one contiguous run, into a region of their own: they are read once per launch, so they always come from
-//     beyond the L2 and must not sit in the delivery of every block), then the blocks of the strip (16 columns
-//     of B = ONE contiguous run of 16 K elements: every DMA instruction moves eight whole 128-byte lines).  A
-//     loader's only vector-memory operations are these DMAs, the same number per image, so "my pieces of image u
-//     have landed" is an exact counted s_waitcnt vmcnt;
+//   * the loader waves stream a sequence of 16 x K images through an LDS ring by LDS-DMA: first the W * PW row
+//     panels of the group (16 rows of A gathered by row id: a row is K contiguous elements; fragment-shaped
+//     loads of the same rows straight into the consumers' registers - 16 rows x 64 bytes per instruction -
+//     took 11 000 cycles per workgroup, measured), then the item's entry words (one contiguous run, into a
+//     region of their own: they are read once per launch, so they always come from beyond the L2 and must not
+//     sit in the delivery of every block), then the blocks of the strip (16 columns of B = ONE contiguous run
+//     of 16 K elements: every DMA instruction moves eight whole 128-byte lines).  A loader's only vector-memory
+//     operations are these DMAs, the same number per image, so "my pieces of image u have landed" is an exact
+//     counted s_waitcnt vmcnt;
 //   * fp32 operands (SRC32): each loader then rounds ITS pieces to fp16 / bf16 (the casts of convertOperands) and
 //     writes them into a second, shallow ring of 16-bit images in the XOR-swizzled layout the MFMA fragment reads
 //     want.  Measured (tools/probes): a wave alone on its SIMD issues one vector instruction per 4-5 cycles, and
@@ -20,14 +23,15 @@
 //     once the loader itself has converted it), so all of it but one group is in flight;
 //   * the workgroup barrier of a group of NBB images publishes them (counted vmcnt + barrier: the only ordering
 //     LDS-DMA data has);
-//   * consumer wave w owns panels w * PW .. w * PW + PW - 1 of the group: it loads their A fragments itself, once,
-//     while the ring fills (as images of the stream the panels cost a barrier step each, as many as the blocks of
-//     the strip), and keeps them in registers.  Per block of B it reads the B fragments (ds_read_b128), issues
+//   * consumer wave w owns panels w * PW .. w * PW + PW - 1 of the group: it takes their A fragments from the
+//     16-bit images and keeps them in registers.  Per block of B it reads the B fragments (ds_read_b128), issues
 //     PW * KS MFMAs, drops the accumulators into its private LDS slab and lets one lane per stored entry carry a
 //     value from the slab to P: the sparse mask costs one store per ENTRY instead of a test per cell.  Its only
-//     vector-memory operations in the loop are those stores, which nothing waits for.  The loop is software-
-//     pipelined by hand (fragments of block b + 1 requested before block b's MFMAs, block b - 1's values stored
-//     behind them): run block after block it is a chain of four LDS round trips.
+//     vector-memory operations in the loop are those stores, which nothing waits for.  A consumer is alone on its
+//     SIMD and issues in order, so nothing overlaps unless the program order says so (measured: fragments -> MFMAs
+//     -> slab -> entries -> store run block after block took ~1000 cycles per block, the MFMAs 256 of them): the
+//     loop is software-pipelined by hand, block b - 1's write-back and block b + 1's fragment requests sit
+//     BETWEEN block b's MFMAs (sched_barrier fences keep them there).
 // Ring accounting.  16-bit operands: consumers read the DMA ring itself, which holds DG + 2 groups: the loaders
 // refill the slots of group g - 2 after passing barrier g - 1, which every consumer reaches only after its reads
 // of group g - 2 have returned.  fp32 operands: the 16-bit ring holds two groups (written for g while g - 1 is
@@ -123,10 +127,11 @@ denseSweep(const void* __restrict__ Aop, const void* __restrict__ Bop, const uin
     static_assert(MYD * DG * NBB <= 63, "vmcnt is 6 bits");
     constexpr uint32_t S16 = SRC32 ? 2u * NBB : S;                         // slots of the ring the consumers read
     constexpr uint32_t GP = W * PW;                                        // panels per row group
+    static_assert(GP % NBB == 0, "the panels of a group fill whole barrier groups");
     constexpr uint32_t slabFloats = PW * 4u * 64u;
     static_assert(PW * 16 <= 64 && PW * 4 * 64 <= 1024, "entry word: 6 bits of row, 10 bits of slab slot");
 
-    // LDS: DMA ring | W slabs | W rowStart tables | (unused) | entry words | (fp32 operands) 16-bit ring
+    // LDS: DMA ring | W slabs | W rowStart tables | row ids of the group | entry words | (fp32 operands) 16-bit ring
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr uint32_t ringBytes = S * imgBytes;
     constexpr uint32_t slabAt = ringBytes, rowLdsAt = slabAt + W * slabFloats * 4u, rowIdsAt = rowLdsAt + W * 16u * PW * 4u;
@@ -141,8 +146,8 @@ denseSweep(const void* __restrict__ Aop, const void* __restrict__ Bop, const uin
     // the item's entry words: one run [wordBase, wordEnd), moved as WI pseudo-images of wordImageBytes (whole barrier groups)
     const uint32_t wordBase = starts[item.startsBase], wordEnd = starts[item.startsBase + W * (nb + 1u) - 1u];
     const uint32_t WI = ((wordEnd - wordBase) * 4u + wordImageBytes * NBB - 1u) / (wordImageBytes * NBB) * NBB;
-    const uint32_t firstBlockImage = WI;
-    const uint32_t total = firstBlockImage + nb;                           // images: entry words, blocks of B
+    const uint32_t firstBlockImage = GP + WI;
+    const uint32_t total = firstBlockImage + nb;                           // images: panels of A, entry words, blocks of B
     const uint32_t numGroups = (total + NBB - 1u) / NBB;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -150,6 +155,11 @@ denseSweep(const void* __restrict__ Aop, const void* __restrict__ Bop, const uin
     if (wave >= (uint32_t)W) {
         // ------------------------------------------------------------------ loader
         const uint32_t q = wave - W;
+        uint32_t* rowIds = reinterpret_cast<uint32_t*>(lds + rowIdsAt);
+        // the group's row ids (every loader writes the same table, and reads it only after its own writes)
+#pragma unroll
+        for (uint32_t t = 0; t < GP * 16u; t += 64u)
+            if (t + lane < GP * 16u) rowIds[t + lane] = panelRows[(size_t)item.group * (GP * 16u) + t + lane];
         // my pieces of an image: DMA instruction d = q + NL m moves piece slots 64 d .. 64 d + 63; lane l's piece is
         // 16 bytes at `pieceOff` of column (or row) `colOf` (fp32: kept in fetch order, only this loader reads it back;
         // 16-bit: XOR-swizzled on the source address, the consumers read it)
@@ -170,8 +180,16 @@ denseSweep(const void* __restrict__ Aop, const void* __restrict__ Bop, const uin
         auto issue = [&](uint32_t u) {
             uint8_t* dst = lds + (u % S) * imgBytes;
             if (SWEEP_LAB_SKIP(5)) return;
-            if (u < firstBlockImage) {                                       // entry words (reads past the run stay inside `words`: its slack)
-                const uint32_t piece = u * wordImageBytes;
+            if (u < GP) {                                                    // a row panel of A
+#pragma unroll
+                for (uint32_t m = 0; m < MYD; ++m) {
+                    const uint32_t row = rowIds[u * 16u + colOf[m]];
+                    const uint8_t* src = Ab + (size_t)row * colBytes + pieceOff[m];
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + dstOff[m]), 16, 0, 0);
+                }
+            } else if (u < firstBlockImage) {                                // entry words (reads past the run stay inside `words`: its slack)
+                const uint32_t piece = (u - GP) * wordImageBytes;
 #pragma unroll
                 for (uint32_t m = 0; m < MYD; ++m) {
                     const uint32_t off = min(piece + (q + (uint32_t)NL * m) * 1024u, kSweepItemWords * 4u - 1024u);
@@ -193,7 +211,7 @@ denseSweep(const void* __restrict__ Aop, const void* __restrict__ Bop, const uin
         // fp32 operands: round my pieces of image u into the 16-bit ring
         auto convert = [&](uint32_t u) {
             if constexpr (SRC32) {
-                if (u < firstBlockImage) return;                             // (entry words)
+                if (u >= GP && u < firstBlockImage) return;                  // (entry words)
                 if (SWEEP_LAB_SKIP(6)) return;
                 const uint8_t* src = lds + (u % S) * imgBytes;
                 uint8_t* dst = lds + ring16At + (u % S16) * img16;
@@ -243,7 +261,7 @@ denseSweep(const void* __restrict__ Aop, const void* __restrict__ Bop, const uin
             waitSum += w1 - w0;
             barSum += w2 - w1;
             if (g == 0) tFirst = w1;
-            if (g == WI / NBB) tPanels = w2;
+            if (g == GP / NBB - 1u) tPanels = w2;
 #endif
         }
 #ifdef BSMR_SWEEP_STAMPS
@@ -275,22 +293,12 @@ denseSweep(const void* __restrict__ Aop, const void* __restrict__ Bop, const uin
         for (int s = 0; s < KS; ++s) frag[s] = *reinterpret_cast<const u32x4*>(col + (((4u * s + g) ^ (r & SW16)) << 4));
     };
 
-    // A fragments of my panels: lane (r, g) holds k = 32 s + 8 g .. + 7 of row r, rounded like convertOperands does
+    // A fragments of my panels, taken from the 16-bit images as the panels of the group stream by
     u32x4 a[PW][KS];
 #pragma unroll
-    for (int j = 0; j < PW; ++j) {
-        const uint32_t row = panelRows[((size_t)item.group * GP + wave * PW + j) * 16u + r];
-        const uint8_t* aRow = Ab + ((size_t)row * K + g * 8u) * ESZ;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            if constexpr (SRC32) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(aRow + s * 128);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(aRow + s * 128 + 16);
-                a[j][s] = packLowp<MODE>(lo, hi);
-            } else {
-                a[j][s] = *reinterpret_cast<const u32x4*>(aRow + s * 64);
-            }
-        }
+    for (uint32_t t = 0; t < GP; ++t) {
+        if (t % NBB == 0) sweepBarrier();
+        if (t / PW == wave) request(t, a[t % PW]);
     }
     // the entry words pass by (pseudo-images: nothing to take from the ring)
     for (uint32_t t = 0; t < WI; t += NBB) sweepBarrier();
@@ -299,72 +307,105 @@ denseSweep(const void* __restrict__ Aop, const void* __restrict__ Bop, const uin
     uint64_t barSum = 0;
 #endif
 
-    // Block b's step, software-pipelined by hand:
-    //   1. pass the barrier of block b + 1's group if it starts one, and request block b + 1's fragments and entry words,
-    //   2. issue block b's MFMAs,
-    //   3. store what block b - 1's entries fetched from the slab (requested in the previous step),
-    //   4. write block b's accumulators to the slab and request its entries' values and row bases (LDS serves a wave
-    //      in order, so these writes cannot overtake the reads of step 3's values, which were issued earlier).
+    // Block b's step, in program order (the wave issues in order; the fences keep the compiler from regrouping):
+    //   B  the MFMAs of k step 0 (PW of them: 16 cycles of matrix pipe each)
+    //   C  block b - 1's write-back, first half: its accumulators into the slab, then the slab value and the row
+    //      base of each of its entries (LDS serves a wave in order: the reads see the writes, and the NEXT step's
+    //      writes cannot overtake these reads)
+    //   D  the MFMAs of k steps 1 .. KS - 1; behind k step s the fragment of k step s - 1 of block b + 1 is
+    //      requested into the registers that k step has just released (first the barrier, if b + 1 starts a group)
+    //   E  block b - 1's write-back, second half: one store per entry (the reads of C returned long ago), and the
+    //      entry words of block b + 1
     uint32_t s0 = __builtin_amdgcn_readlane(st, 0);
-    bool pend = false;
-    float pendVal = 0.f;
-    uint32_t pendBase = 0, pendOff = 0;          // (added when the store is issued: the row base is still on its way from LDS)
-    auto step = [&](uint32_t b, const u32x4 (&cur)[KS], u32x4 (&next)[KS], uint32_t wCur, uint32_t& wNext) {
-        const uint32_t s1 = __builtin_amdgcn_readlane(st, b + 1u);
-        if (b + 1u < nb) {
-            if ((firstBlockImage + b + 1u) % NBB == 0) {
-                SWEEP_CLOCK(b0);
-                sweepBarrier();
-#ifdef BSMR_SWEEP_STAMPS
-                barSum += __builtin_amdgcn_s_memtime() - b0;
-#endif
-            }
-            request(firstBlockImage + b + 1u, next);
-            wNext = wordLds[s1 + lane];          // (64 words from the list's start: what lies past its end is not used)
-        }
-        f32x4 acc[PW];
-        if (!SWEEP_LAB_SKIP(1)) {
-#pragma unroll
-            for (int j = 0; j < PW; ++j) acc[j] = mfma16<MODE>(a[j][0], cur[0], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-            for (int s = 1; s < KS; ++s)
-#pragma unroll
-                for (int j = 0; j < PW; ++j) acc[j] = mfma16<MODE>(a[j][s], cur[s], acc[j]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < PW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (pend && !SWEEP_LAB_SKIP(4)) P[pendBase + pendOff] = pendVal;
+    auto writeBack = [&](const f32x4 (&accPrev)[PW], uint32_t wPrev, float& val, uint32_t& base) {
         if (!SWEEP_LAB_SKIP(2)) {
 #pragma unroll
-            for (int j = 0; j < PW; ++j) *reinterpret_cast<f32x4*>(slab + (j * 64 + lane) * 4) = acc[j];
+            for (int j = 0; j < PW; ++j) *reinterpret_cast<f32x4*>(slab + (j * 64 + lane) * 4) = accPrev[j];
         }
-        const uint32_t n = s1 - s0;
-        pend = lane < n && wCur != kSweepNoEntry;
         if (!SWEEP_LAB_SKIP(3)) {
-            pendVal = slab[wCur & (slabFloats - 1u)];
-            pendBase = rowLds[(wCur >> 10) & (16u * PW - 1u)];
+            val = slab[wPrev & (slabFloats - 1u)];
+            base = rowLds[(wPrev >> 10) & (16u * PW - 1u)];
         }
-        pendOff = wCur >> 16;
-        if (n > 64u) {                                                       // (rare: a step with more than 64 entries)
-            for (uint32_t e = 64u + lane; e < n; e += 64u) {
-                const uint32_t w = wordLds[s0 + e];
+    };
+    auto storeEntries = [&](uint32_t wPrev, float val, uint32_t base, uint32_t s0Prev, uint32_t nPrev) {
+        if (lane < nPrev && wPrev != kSweepNoEntry && !SWEEP_LAB_SKIP(4)) P[base + (wPrev >> 16)] = val;
+        if (nPrev > 64u) {                                                   // (rare: a step with more than 64 entries)
+            for (uint32_t e = 64u + lane; e < nPrev; e += 64u) {
+                const uint32_t w = wordLds[s0Prev + e];
                 if (w != kSweepNoEntry) P[rowLds[(w >> 10) & 63u] + (w >> 16)] = slab[w & 1023u];
             }
         }
-        s0 = s1;
     };
     if (nb) {
-        u32x4 f0[KS], f1[KS];
-        uint32_t w0 = kSweepNoEntry, w1 = kSweepNoEntry;
-        if (firstBlockImage % NBB == 0) sweepBarrier();
-        request(firstBlockImage, f0);
-        w0 = wordLds[s0 + lane];
-        for (uint32_t b = 0; b < nb; b += 2u) {
-            step(b, f0, f1, w0, w1);
-            if (b + 1u < nb) step(b + 1u, f1, f0, w1, w0);
+        u32x4 frag[KS];
+        f32x4 accA[PW], accB[PW];
+        uint32_t wPrev = kSweepNoEntry, s0Prev = 0, nPrev = 0;
+        sweepBarrier();                                                      // (the group of block 0)
+        request(firstBlockImage, frag);
+        uint32_t wHere = wordLds[s0 + lane];     // (64 words from the list's start: what lies past its end is not used)
+        auto step = [&](uint32_t b, f32x4 (&acc)[PW], const f32x4 (&accPrev)[PW], auto firstTag) {
+            constexpr bool FIRST = decltype(firstTag)::value;
+            const uint32_t s1 = __builtin_amdgcn_readlane(st, b + 1u);
+            const bool more = b + 1u < nb;
+            float val = 0.f;
+            uint32_t base = 0;
+            if (!SWEEP_LAB_SKIP(1)) {
+#pragma unroll
+                for (int j = 0; j < PW; ++j) acc[j] = mfma16<MODE>(a[j][0], frag[0], f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!FIRST) writeBack(accPrev, wPrev, val, base);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 1; s < KS; ++s) {
+                if (!SWEEP_LAB_SKIP(1)) {
+#pragma unroll
+                    for (int j = 0; j < PW; ++j) acc[j] = mfma16<MODE>(a[j][s], frag[s], acc[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    if (s == 1 && (firstBlockImage + b + 1u) % NBB == 0) {
+                        SWEEP_CLOCK(b0);
+                        sweepBarrier();
+#ifdef BSMR_SWEEP_STAMPS
+                        barSum += __builtin_amdgcn_s_memtime() - b0;
+#endif
+                    }
+                    const uint8_t* col = ring16 + ((firstBlockImage + b + 1u) % S16) * img16 + r * col16;
+                    frag[s - 1] = *reinterpret_cast<const u32x4*>(col + (((4u * (s - 1) + g) ^ (r & SW16)) << 4));
+                    if (s == KS - 1)
+                        frag[s] = *reinterpret_cast<const u32x4*>(col + (((4u * s + g) ^ (r & SW16)) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (KS == 1) {
+                if (more) {
+                    if ((firstBlockImage + b + 1u) % NBB == 0) sweepBarrier();
+                    request(firstBlockImage + b + 1u, frag);
+                }
+            }
+            if constexpr (!FIRST) storeEntries(wPrev, val, base, s0Prev, nPrev);
+            wPrev = wHere;
+            s0Prev = s0;
+            nPrev = s1 - s0;
+            s0 = s1;
+            if (more) wHere = wordLds[s0 + lane];
+        };
+        step(0, accA, accB, std::true_type{});
+        uint32_t b = 1;
+        for (; b + 1u < nb; b += 2u) {
+            step(b, accB, accA, std::false_type{});
+            step(b + 1u, accA, accB, std::false_type{});
         }
-        if (pend) P[pendBase + pendOff] = pendVal;
+        float val = 0.f;
+        uint32_t base = 0;
+        if (b < nb) {
+            step(b, accB, accA, std::false_type{});
+            writeBack(accB, wPrev, val, base);
+        } else {
+            writeBack(accA, wPrev, val, base);
+        }
+        storeEntries(wPrev, val, base, s0Prev, nPrev);
     }
 #ifdef BSMR_SWEEP_STAMPS
     if (stamps && wave == 0 && lane == 0) {

@@ -191,7 +191,8 @@ typedef struct bsmr_plan_options {
                                                                                                               [SWEEP_PANELS] */
     int32_t  sweep_strip_blocks;    /* 16-column blocks of B per work item: 0 = from the plan's shape; <= 63   [SWEEP_BLOCKS] */
     int32_t  sweep_fp32;            /* sweep kernel on the caller's fp32 operands, rounded in registers (no conversion
-                                       pass): -1 = for K <= 128 (default), 0 = never, 1 = whenever K <= 128    [SWEEP_FP32] */
+                                       pass; a residue then runs its fp32 kernel): -1 = for K <= 128 when the plan has no
+                                       residue (default), 0 = never, 1 = whenever K <= 128                     [SWEEP_FP32] */
     int32_t  sweep_waves;           /* consumer waves per workgroup: 0 = 4; 4, 8                                [SWEEP_WAVES] */
     int32_t  sweep_per_cu;          /* workgroups per CU the LDS ring is sized for: 0 = 1; 1, 2 (2: four consumer waves only)
                                                                                                               [SWEEP_PER_CU] */
@@ -366,7 +367,9 @@ int bsmr_sddmm_lowp(bsmr_plan *plan, uint32_t K, const void *A16_dev, const void
  * every range is a problem of its own: shard_descs[i] is the RPHM of rows [row_begin[i], row_begin[i+1]) with LOCAL
  * row ids (built by the host pipeline on that slice), devices[i] the GPU it lives on.  A step runs bsmr_sddmm on
  * every device and gathers the compact outputs to devices[0] with one RCCL send/recv group (communicators are
- * created once, in bsmr_sharded_create); P in S's CSR order is the concatenation of the shards' outputs. */
+ * created once, in bsmr_sharded_create, over the distinct devices of the list); P in S's CSR order is the concatenation
+ * of the shards' outputs.  A device may be listed more than once (more shards than GPUs): a shard on the root's device
+ * hands its part over with a device-to-device copy.  A range without rows or entries takes no part in a step. */
 typedef struct bsmr_sharded bsmr_sharded;
 typedef struct bsmr_sharded_timing {
     float    step_ms;      /* device time of one step (SDDMM on every device + gather), max over devices */

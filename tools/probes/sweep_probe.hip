@@ -52,14 +52,14 @@ struct Variant {
 static const Variant kVariants[] = {
     V("k128_f32_w4p4_n4b1", 4, 4, 0, true, 4, 4, 1, 1), V("k128_f32_w4p4_n4b2", 4, 4, 0, true, 4, 4, 1, 2),
     V("k128_f32_w4p4_n8b1", 4, 4, 0, true, 4, 8, 1, 1), V("k128_f32_w4p4_n8b2", 4, 4, 0, true, 4, 8, 1, 2),
-    V("k128_f32_w4p4_n8b4", 4, 4, 0, true, 4, 8, 1, 4), V("k128_f32_w4p4x2_n4b1", 4, 4, 0, true, 4, 4, 2, 1),
-    V("k128_f32_w4p2x2_n4b1", 4, 2, 0, true, 4, 4, 2, 1), V("k128_f32_w8p2_n8b1", 4, 2, 0, true, 8, 8, 1, 1),
-    V("k128_f32_w8p2_n8b2", 4, 2, 0, true, 8, 8, 1, 2), V("k128_h_w4p4_n8b1", 4, 4, 0, false, 4, 8, 1, 1),
-    V("k128_h_w4p4_n4b2", 4, 4, 0, false, 4, 4, 1, 2),
-    V("k512_b_w4p2_n4b1", 16, 2, 1, false, 4, 4, 1, 1), V("k512_b_w4p2_n8b1", 16, 2, 1, false, 4, 8, 1, 1),
-    V("k512_b_w4p2_n8b2", 16, 2, 1, false, 4, 8, 1, 2), V("k512_b_w8p1_n8b1", 16, 1, 1, false, 8, 8, 1, 1),
-    V("k512_b_w8p1_n8b2", 16, 1, 1, false, 8, 8, 1, 2),
+    V("k128_f32_w4p4_n8b4", 4, 4, 0, true, 4, 8, 1, 4), V("k128_f32_w8p2_n8b2", 4, 2, 0, true, 8, 8, 1, 2),
+    V("k128_f32_w8p2_n8b4", 4, 2, 0, true, 8, 8, 1, 4), V("k128_h_w4p4_n8b2", 4, 4, 0, false, 4, 8, 1, 2),
+    V("k128_h_w4p4_n4b2", 4, 4, 0, false, 4, 4, 1, 2), V("k128_h_w4p4_n4b4", 4, 4, 0, false, 4, 4, 1, 4),
+    V("k512_b_w4p2_n4b1", 16, 2, 1, false, 4, 4, 1, 1), V("k512_b_w4p2_n4b2", 16, 2, 1, false, 4, 4, 1, 2),
+    V("k512_b_w8p1_n4b2", 16, 1, 1, false, 8, 4, 1, 2), V("k512_b_w8p1_n8b2", 16, 1, 1, false, 8, 8, 1, 2),
+    V("k512_b_w8p2_n4b2", 16, 2, 1, false, 8, 4, 1, 2),
 };
+
 
 
 static uint16_t toF16(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
