@@ -1909,6 +1909,14 @@ int bsmr_plan_get_stats(const bsmr_plan* p, bsmr_plan_stats* out) {
 int bsmr_plan_dense_choice(const bsmr_plan* plan, uint32_t K, uint32_t* group_size, uint64_t* tiles,
                            uint64_t* union_columns) {
     if (!plan) return BSMR_ERR_INVALID_ARG;
+    if (sweepEngine(plan)) {   // (of the call prepared last) rows and columns of K elements streamed: every item its panels and its strip
+        const SweepFormatDev& w = plan->sweeps[(size_t)plan->sweepNow];
+        const uint64_t ncb = (plan->N + 15u) / 16u;
+        if (group_size) *group_size = w.W * w.PW;
+        if (tiles) *tiles = (uint64_t)w.numGroups * w.W * w.PW * ncb;
+        if (union_columns) *union_columns = (uint64_t)w.numItems * w.W * w.PW * 16u + (uint64_t)w.numGroups * ncb * 16u;
+        return BSMR_OK;
+    }
     if (tilesEngine(plan, K)) {
         const uint32_t h = chooseTileGroup(plan, K);
         const bsmr::TileCensus& c = censusOf(plan, h);

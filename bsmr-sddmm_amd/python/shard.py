@@ -3,7 +3,9 @@
 The reference is single-GPU; this layer is new.  Row panels are independent (a
 panel owns a disjoint set of output entries), so:
 
-  * the rows of S are cut into `world` contiguous ranges of (nearly) equal nnz;
+  * the rows of S are cut into `world` contiguous ranges of (nearly) equal COST
+    (entries plus a fixed charge per non-empty row, cuts at multiples of 16 rows:
+    partition_rows_by_cost / bsmr_partition_rows_by_cost);
     rank r owns range r: its slice of S (a CSR with local row ids), the matching
     rows of A, and a full copy of B.  Each rank runs the whole BSMR pipeline
     (cluster, reorder, split, plan) on its own slice - clustering never crosses a

@@ -178,11 +178,34 @@ def community_graph(n=4096, avg_degree=64, communities=8, inside=0.8, seed=3):
     return _rows_to_csr(n, n, per_row)
 
 
+def _distinct(rng, lo, hi, k, taken=None):
+    """k distinct integers of [lo, hi) (not in the sorted array `taken`), drawn with replacement until enough are distinct."""
+    span = hi - lo
+    k = min(k, span - (0 if taken is None else int(np.searchsorted(taken, hi) - np.searchsorted(taken, lo))))
+    if k <= 0:
+        return np.empty(0, dtype=np.int64)
+    if k * 2 > span:                       # most of the range: a permutation is cheaper than rejection
+        c = lo + rng.permutation(span)
+        if taken is not None:
+            c = c[~np.isin(c, taken)]
+        return c[:k]
+    got = np.empty(0, dtype=np.int64)
+    while got.size < k:
+        c = rng.integers(lo, hi, size=int((k - got.size) * 1.25) + 16)
+        if taken is not None:
+            c = c[~np.isin(c, taken)]
+        both = np.concatenate([got, c])
+        _, first = np.unique(both, return_index=True)
+        got = both[np.sort(first)]         # distinct, in the order drawn
+    return got[:k]
+
+
 def reddit_shard_like(rows=29121, cols=232965, avg_degree=492, communities=41, inside=0.8, first_row=0, seed=3):
     """One row shard of a reddit-like graph (BASELINE configs[3]: 232 965^2, nnz 114.6 M, cut into 8 row ranges):
     rows [first_row, first_row + rows) of a graph over `cols` vertices with power-law out-degrees (mean
     `avg_degree`) and `communities` planted communities (contiguous id ranges; `inside` of a row's edges stay in
-    its own).  Vectorised: a row's duplicates are dropped, so nnz is a little below rows * avg_degree."""
+    its own).  A row stores exactly its degree (distinct columns are drawn until there are enough), so the shard holds
+    rows * avg_degree = 14.3 M entries: an eighth of reddit's 114.6 M."""
     rng = np.random.default_rng(seed)
     deg = _fit_counts(rng.pareto(1.5, size=rows) + 0.2, rows * avg_degree, cols // 4)
     size = -(-cols // communities)
@@ -191,9 +214,10 @@ def reddit_shard_like(rows=29121, cols=232965, avg_degree=492, communities=41, i
         k = int(deg[i])
         c0 = ((first_row + i) // size) * size
         c1 = min(c0 + size, cols)
-        own = rng.random(k) < inside
-        c = np.where(own, rng.integers(c0, c1, size=k), rng.integers(0, cols, size=k))
-        per_row.append(np.unique(c))
+        k_in = min(int(round(k * inside)), (c1 - c0) * 9 // 10)
+        own = np.sort(_distinct(rng, c0, c1, k_in))
+        other = _distinct(rng, 0, cols, k - own.size, taken=own)
+        per_row.append(np.sort(np.concatenate([own, other])).astype(np.uint32))
     return _rows_to_csr(rows, cols, per_row)
 
 
@@ -209,7 +233,9 @@ def reddit_like_rows(first_row, rows, n=232965, avg_degree=492, communities=41, 
     """Rows [first_row, first_row + rows) of THE reddit-like graph over n vertices (reddit_like_degrees; `communities`
     planted communities in contiguous id ranges, `inside` of a row's edges in its own).  Rows are generated in
     globally aligned chunks of 1024 from a generator seeded by (seed, chunk), so any cut of the rows gives the same
-    graph: rank r of a sharded run builds only its own range.  Duplicates inside a row are dropped."""
+    graph: rank r of a sharded run builds only its own range.  A row STORES exactly its degree (distinct columns are
+    drawn until there are enough, a community can be filled to nine tenths), so the graph holds n * avg_degree entries:
+    114.6 M at the default size, reddit's count."""
     deg = reddit_like_degrees(n, avg_degree, seed) if degrees is None else degrees
     size = -(-n // communities)
     per_row = []
@@ -220,10 +246,11 @@ def reddit_like_rows(first_row, rows, n=232965, avg_degree=492, communities=41, 
             k = int(deg[i])
             c0 = (i // size) * size
             c1 = min(c0 + size, n)
-            own = rng.random(k) < inside
-            c = np.where(own, rng.integers(c0, c1, size=k), rng.integers(0, n, size=k))
+            k_in = min(int(round(k * inside)), (c1 - c0) * 9 // 10)
+            own = np.sort(_distinct(rng, c0, c1, k_in))
+            other = _distinct(rng, 0, n, k - own.size, taken=own)
             if first_row <= i < last:
-                per_row.append(np.unique(c))
+                per_row.append(np.sort(np.concatenate([own, other])).astype(np.uint32))
     return _rows_to_csr(last - first_row, n, per_row)
 
 

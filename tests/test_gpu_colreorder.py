@@ -43,6 +43,24 @@ def test_device_column_reordering_equals_the_host_arrays(engine, name, pattern, 
         assert np.array_equal(got[k], want[k]), (name, k)
 
 
+@pytest.mark.parametrize("delta", [0.0, 0.2, 1.1])
+def test_device_column_reordering_equals_the_numpy_oracle(engine, delta):
+    """The device arrays against oracle/bsmr_oracle.py directly (col_reordering + rphm restate src/colReordering.cu:274-404
+    and src/BSMR.cpp:83-265 line by line), not through the host product: a row order that is NOT the pipeline's own
+    (reversed identity with the empty rows left out) and a pattern whose last panel is ragged."""
+    import bsmr_oracle
+    rows, cols, ro, ci = synth.random_pattern(75, 130, 1900, seed=31, empty_rows=5)
+    order = np.array([r for r in range(rows - 1, -1, -1) if ro[r + 1] > ro[r]], dtype=np.uint32)
+    cr = bsmr_oracle.col_reordering(rows, cols, ro, ci, order, delta)
+    rp = bsmr_oracle.rphm(rows, cols, ro, ci, order, cr)
+    assert bsmr_oracle.check_rphm_invariants(rows, cols, ro, ci, order, cr, rp)
+    st, got, _ = engine.col_reorder_device(rows, cols, ro, ci, order, delta, device=0)
+    assert st == engine.OK
+    want = {**cr, **rp}
+    for k in ARRAYS:
+        assert np.array_equal(got[k], want[k]), k
+
+
 def test_device_column_reordering_in_the_pipeline_and_its_time(engine, oracle, capsys):
     """BSMR::colReordering on the device (BSMR_COLREORDER=device; automatic from 4 M entries): the pipeline's arrays,
     its check_rphm invariants and the SDDMM are unchanged; times of both paths are printed (mycielskian15: 5.6 M entries)."""

@@ -329,6 +329,24 @@ def test_error_codes_on_device(engine):
         assert st == engine.ERR_BAD_PLAN
     st, plan = engine.plan_from_arrays(rows, cols, csr.nnz, pipe.arrays(), device=99)
     assert st == engine.ERR_NO_DEVICE
+    # offsets that do not ascend are rejected before any packer indexes with them - the host packer and the device packer
+    # (pack_on_device = 1) alike; a hybrid pattern so that both offset arrays are in use
+    rows, cols, ro, ci = synth.community_graph(n=400, avg_degree=40, communities=4, seed=5)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    good = engine.Pipeline(csr, alpha=0.3, delta=0.2, device=-1).arrays()
+    assert good["blockOffsets"][-1] > 0 and good["sparseValueOffsets"][-1] > 0
+    for name in ("blockOffsets", "sparseValueOffsets"):
+        for on_device in (0, 1):
+            bad = dict(good)
+            bad[name] = good[name].copy()
+            mid = bad[name].size // 2
+            bad[name][mid], bad[name][mid + 1] = good[name][mid + 1] + 7, good[name][mid]      # a descent in the middle
+            st, plan = engine.plan_from_arrays(rows, cols, csr.nnz, bad, device=0,
+                                               options=engine.plan_options(pack_on_device=on_device, fold_dense_below=0))
+            assert st == engine.ERR_BAD_PLAN, (name, on_device, st)
+    st, plan = engine.plan_from_arrays(rows, cols, csr.nnz, good, device=0, options=engine.plan_options(pack_on_device=1, fold_dense_below=0))
+    assert st == engine.OK
+    engine.plan_destroy(plan)
 
 
 @pytest.mark.shipping_rules
@@ -384,12 +402,18 @@ def test_cop20k_like_with_node_blocks_runs_both_kernels_by_default(engine, oracl
 
 
 @pytest.mark.shipping_rules
-@pytest.mark.parametrize("delta", [0.0, 0.1, 1.1])
-def test_dlmc_like_4096_k512_bf16(engine, oracle, delta, capsys):
+@pytest.mark.parametrize("split", ["shipping rules", "RPHM split as is"])
+@pytest.mark.parametrize("delta", [0.0, 0.1, 0.3, 0.5, 1.1])
+def test_dlmc_like_4096_k512_bf16(engine, oracle, monkeypatch, delta, split, capsys):
     """BASELINE configs[4] at full size: 4096 x 4096, 90 % sparse (i.i.d. Bernoulli(0.1), 1.68 M entries), K = 512,
-    bf16 operands / fp32 accumulate, at the two ends and one interior point of the delta sweep; default plan rules.
-    Zero checkData failures against sddmm_cpu (bf16 meets the reference's 1e-3 only from
-    K = 512 on U[0,2) data); the measured maximum relative error is printed."""
+    bf16 operands / fp32 accumulate, over the delta sweep.  Twice: with the shipping plan rules (which promote the
+    whole residue of this pattern to the MFMA path: every delta runs the all-dense plan), and with the RPHM's split
+    taken as is (no promotion, no folding: delta >= 0.1 runs the hybrid - the bf16 residue kernel at K = 512 on
+    1.4 to 1.68 M entries - or the residue alone).  Zero checkData failures against sddmm_cpu (SURVEY.md appendix B:
+    bf16 meets the reference's 1e-3 only from K = 512 on U[0,2) data); the measured maximum relative error is printed."""
+    if split == "RPHM split as is":
+        monkeypatch.setenv("BSMR_PROMOTE_AVERAGE", "0")
+        monkeypatch.setenv("BSMR_FOLD_DENSE_BELOW", "0")
     rows, cols, ro, ci = synth.bernoulli()
     assert rows == cols == 4096
     K = 512
@@ -400,9 +424,11 @@ def test_dlmc_like_4096_k512_bf16(engine, oracle, delta, capsys):
     rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
     st = pipe.plan_stats()
     with capsys.disabled():
-        print(f"\n[configs[4] delta={delta}] bf16 K=512: max relative error {rel.max():.3e} (tolerance 1e-3), "
+        print(f"\n[configs[4] delta={delta}, {split}] bf16 K=512: max relative error {rel.max():.3e} (tolerance 1e-3), "
               f"dense entries {st['num_dense_entries']}, residue {st['num_sparse_entries']}")
     assert rel.max() < 1e-3
+    if split == "RPHM split as is":
+        assert (st["num_sparse_entries"] > 0) == (delta >= 0.1) and st["promoted_sparse_entries"] == 0
 
 
 @pytest.mark.parametrize("name,pattern,K,mode", [
@@ -686,7 +712,7 @@ def test_residue_blocks_are_promoted_to_dense_blocks(engine, oracle, monkeypatch
 
 def test_reddit_shard_scale(engine, oracle):
     """BASELINE configs[3] at the size one of 8 GPUs sees: a 29 121 x 232 965 row shard of a reddit-like graph
-    (12.1 M stored entries, rows up to ~17 000 entries), K = 256, natural row order (the clustering of this shard
+    (14.3 M stored entries, rows up to ~58 000 entries), K = 256, natural row order (the clustering of this shard
     is timed by bench.py --workload reddit_shard_k256).  Every entry against the CPU loop and the path models."""
     rows, cols, ro, ci = synth.reddit_shard_like()
     assert ci.size > 12_000_000
