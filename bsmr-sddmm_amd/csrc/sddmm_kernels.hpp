@@ -526,20 +526,18 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     };
 
-    // 2. first gather, then the A fragments, destinations and row bases, then the second gather: all
-    //    in flight together.  The A loads are issued through inline assembly so that the compiler,
-    //    which cannot count past an LDS-DMA, does not put a vmcnt(0) in front of their first use;
-    //    the counted wait of the first block (all but the youngest KS operations) covers them.
+    // 2. first gather, then destinations and row bases, the A fragments, and the second gather: all in
+    //    flight together.  The A loads are issued through inline assembly so that the compiler, which
+    //    cannot count past an LDS-DMA, does not put a vmcnt(0) in front of their first use; the counted
+    //    wait of the first image (all but the youngest KSL operations) covers them.  The compiler takes
+    //    an asm load's registers for written when the statement ends and may copy them before the data
+    //    has landed (round 2's K = 512 fault; `make check-isa` found more instances of it): so from the
+    //    A loads to the statement that pins the registers behind the wait the code is ONE straight line
+    //    - loads, second gather (issued unconditionally: a wave with a single image gathers it twice),
+    //    wait, pin - with nothing for the register allocator to split a live range at.
     f32x4 acc[MAXB][H];
     gather(0);
     u32x4 a[H][KS];
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-        const uint16_t* aRow = A16 + (size_t)myRow[h] * K + g * 8u;
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[h][s]) : "v"(aRow + s * 32) : "memory");
-    }
     TileRaw tile[MAXB][H];
 #pragma unroll
     for (uint32_t m = 0; m < (uint32_t)MAXB; ++m)
@@ -556,9 +554,20 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
             rowBase[h][i] = WINDOWED ? rowBaseTable[(size_t)itemId * (16u * H) + 16u * h + 4u * g + i]
                                      : rowBaseTable[rowSlot + 16u * h + 4u * g + i];
     const uint32_t units = myCount * SPLIT;
+    static_assert(SLOTS == 2, "the first wait below leaves exactly one image in flight");
 #pragma unroll
-    for (uint32_t u = 1; u + 1 < SLOTS; ++u)
-        if (u < units) gather(u);
+    for (int h = 0; h < H; ++h) {
+        const uint16_t* aRow = A16 + (size_t)myRow[h] * K + g * 8u;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[h][s]) : "v"(aRow + s * 32) : "memory");
+    }
+    gather(min(1u, units - 1u));
+    waitInFlight(1);
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[h][s]));
 #pragma unroll
     for (uint32_t m = 0; m < (uint32_t)MAXB; ++m) {
         if (m >= myCount) break;  // wave-uniform
@@ -568,17 +577,12 @@ denseStream(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
 #pragma unroll
         for (uint32_t half = 0; half < SPLIT; ++half) {
             const uint32_t u = m * SPLIT + half;
-            // slot (u + SLOTS - 1) % SLOTS held image u-1, whose reads returned before its MFMAs
-            if (u + SLOTS - 1 < units) gather(u + SLOTS - 1);
-            const uint32_t younger = min(units - 1u - u, SLOTS - 1u);  // gathers issued after image u's
-            if (younger == 0) waitInFlight(0);
-            else if (younger == 1) waitInFlight(1);
-            else waitInFlight(2);
-            if (u == 0) {  // the A fragments have landed with the first image
-#pragma unroll
-                for (int h = 0; h < H; ++h)
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[h][s]));
+            if (u != 0) {   // (image 0: waited for above, with the A fragments)
+                // slot (u + SLOTS - 1) % SLOTS held image u-1, whose reads returned before its MFMAs
+                if (u + SLOTS - 1 < units) gather(u + SLOTS - 1);
+                const uint32_t younger = min(units - 1u - u, SLOTS - 1u);  // gathers issued after image u's
+                if (younger == 0) waitInFlight(0);
+                else waitInFlight(1);
             }
             const uint8_t* bCol = myLds + (u % SLOTS) * blkBytes + r * rowBytes;
 #pragma unroll
@@ -665,16 +669,7 @@ denseStreamCvt(const float* __restrict__ A, const float* __restrict__ B, const u
     };
 
     gather(0);
-    // the A rows of the panel as fp32 fragments (inline assembly: see denseStream), rounded once they have landed
     f32x4 aLo[KS], aHi[KS];
-    {
-        const float* aRow = A + (size_t)myRow * K + g * 8u;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aLo[s]) : "v"(aRow + s * 32) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aHi[s]) : "v"(aRow + s * 32 + 4) : "memory");
-        }
-    }
     TileRaw tile[MAXB];
 #pragma unroll
     for (uint32_t m = 0; m < (uint32_t)MAXB; ++m)
@@ -686,21 +681,33 @@ denseStreamCvt(const float* __restrict__ A, const float* __restrict__ B, const u
 
     f32x4 acc[MAXB];
     u32x4 a[KS];
+    // the A rows of the panel as fp32 fragments (inline assembly, and one straight line from the loads to the pin behind
+    // the wait: see denseStream), rounded once they have landed
+    {
+        const float* aRow = A + (size_t)myRow * K + g * 8u;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aLo[s]) : "v"(aRow + s * 32) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aHi[s]) : "v"(aRow + s * 32 + 4) : "memory");
+        }
+        gather(min(1u, myCount - 1u));     // (a wave with one block gathers it twice: the wait below stays the same)
+        waitForAllButNewestGather();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            asm volatile("" : "+v"(aLo[s]));
+            asm volatile("" : "+v"(aHi[s]));
+            a[s] = packLowp<MODE>(aLo[s], aHi[s]);
+        }
+    }
 #pragma unroll
     for (uint32_t m = 0; m < (uint32_t)MAXB; ++m) {
         if (m >= myCount) break;  // wave-uniform
-        if (m + 1 < myCount) {
-            gather(m + 1);
-            waitForAllButNewestGather();
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (m == 0) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                asm volatile("" : "+v"(aLo[s]));
-                asm volatile("" : "+v"(aHi[s]));
-                a[s] = packLowp<MODE>(aLo[s], aHi[s]);
+        if (m != 0) {
+            if (m + 1 < myCount) {
+                gather(m + 1);
+                waitForAllButNewestGather();
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
         const uint8_t* bCol = lds + (m & 1u) * blkBytes + r * rowBytes;

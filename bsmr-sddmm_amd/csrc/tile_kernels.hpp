@@ -185,8 +185,11 @@ denseTiles(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
     for (int h = 0; h < H; ++h) asm volatile("" : "+v"(myRow[h]));
 
     // ---- A fragments of the H panels: lane (r, g) holds k = 32 s + 8 g .. + 7 of row r (16 bytes) ----
-    // issued through inline assembly so that the compiler, which cannot count past an LDS-DMA, does not drain
-    // the queue before their first use; the counted wait of the first image covers them (they are older)
+    // issued through inline assembly and waited for on the spot, before the first gather is issued: loads, wait and
+    // the statements that pin the registers behind the wait are one straight line.  (Round 2 left them in flight under
+    // the first gathers, covered by the first image's counted wait; the compiler, for which an asm load's registers
+    // are written when the statement ends, copied some of them in between - `make check-isa`.  The round trip costs
+    // a work item ~500 cycles once.)
     u32x4 a[H][KS];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
@@ -195,6 +198,11 @@ denseTiles(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
         for (int s = 0; s < KS; ++s)
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[h][s]) : "v"(aRow + s * 32) : "memory");
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[h][s]));
 
     // per-lane constants of the gather: DMA instruction j moves piece slots [64 j, 64 j + 64) of an image;
     // slot f = column f / PC, piece f % PC, XOR-swizzled on the SOURCE so that fragment reads are conflict-free
@@ -288,10 +296,6 @@ denseTiles(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16,
             seq[D - 2] = issued;
             waitVmcnt(issued - landed);
             if (u == 0) {
-#pragma unroll
-                for (int h = 0; h < H; ++h)
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[h][s]));
                 BSMR_STAMP(2);
 #ifdef BSMR_LAB_STAMPS
                 if (stamps) tPhase = __builtin_readcyclecounter();

@@ -22,10 +22,11 @@ def run_bench(*args):
 def test_default_bench_line():
     d = run_bench("--steps", "30", "--warmup", "5")
     for key, kind in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
-                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                      ("ms_per_step", float), ("higher_is_better", bool), ("dtype", str), ("data", str),
                       ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert isinstance(d[key], kind), (key, d[key])
     assert d["vs_baseline"] is None                      # BASELINE.md publishes no number for this workload
+    assert "scaling" in d and d["scaling"] is None        # one GPU: neither weak nor strong
     assert (d["n_gpus"], d["steps"], d["warmup"], d["dtype"], d["higher_is_better"]) == (1, 30, 5, "f16", True)
     assert "workload" in d["config"] and "nips" in d["config"]["workload"]
     r = d["roofline"]
