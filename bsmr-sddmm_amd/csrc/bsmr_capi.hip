@@ -1662,6 +1662,11 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         opt.sparsePerItem = o.sparse_entries_per_item > 0 ? o.sparse_entries_per_item : 256;
         opt.forceWideTiles = o.force_tile32 != 0;
         opt.columnOrder = o.column_order != 0;
+        // lab knobs of tools/reddit_traffic_lab.sh (profiles/r03_reddit_traffic.md): other launch orders of the dense items.  None
+        // of them beat the first-column order; they exist in the host packer only, which is then the one that runs.
+        opt.itemOrder = envInt("BSMR_ITEM_ORDER", 0);
+        opt.orderWindow = (uint32_t)envInt("BSMR_ORDER_WINDOW", 8192);
+        opt.itemSpan = (uint32_t)envInt("BSMR_ITEM_SPAN", 0);
         opt.freeResidue = o.free_residue;
         // 0 = 16/32-bit offsets from the row's first dense entry; 1 = 8-bit window offsets,
         // scattered; 2 = 8-bit window offsets, assembled in LDS and stored coalesced
@@ -1681,6 +1686,7 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         uint64_t deviceFormatBytes = 0;
         bool packedOnDevice = false;
         if (opt.group == 1 && opt.columnOrder && opt.staged && !opt.forceWideTiles &&
+            !opt.itemOrder && !opt.itemSpan &&
             (o.pack_on_device > 0 || (o.pack_on_device < 0 && d->block_offsets[P] >= 4096))) {
             DevicePackResult r;
             if ((st = bsmr::packRows(d, pk)) != BSMR_OK) return st;

@@ -104,6 +104,11 @@ struct PackOptions {
     bool staged = true;       // try the staged (LDS window) destination encoding
     bool maskTiles = true;    // ... and from it the mask form (48 bytes per tile) when every tile row's entries are consecutive
     int freeResidue = 0;      // 1: residue in global column order instead of per panel (cross-check only)
+    // launch order of the dense items (with columnOrder): 0 = by first column; 1 = row chunk (1/8 of the items: the XCD's
+    // rows of A stay in its L2), then first column; 2 = column window of orderWindow columns, then group, then column
+    int itemOrder = 0;
+    uint32_t orderWindow = 8192;
+    uint32_t itemSpan = 0;    // > 0: an item's blocks start inside itemSpan columns of its first block's first column
 };
 
 struct PackedPlan {
@@ -421,6 +426,7 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
                         bhi[row] = std::max(bhi[row], v);
                     }
                 bool fits = count < perItem;
+                if (opt.itemSpan && count && out.blockCols[(size_t)b * 16] / opt.itemSpan != out.blockCols[(size_t)itemFirst * 16] / opt.itemSpan) fits = false;
                 for (uint32_t r = 0; r < R; ++r) {
                     if (blo[r] == kNone) continue;
                     if (bhi[r] - blo[r] >= kWindowMax) staged = false;  // one block alone is too wide
@@ -537,10 +543,25 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
         // The per-item arrays of the STAGED form are permuted along.
         std::vector<uint32_t> order(out.denseItems.size());
         for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-            return out.blockCols[(size_t)out.denseItems[a].first * 16] <
-                   out.blockCols[(size_t)out.denseItems[b].first * 16];
-        });
+        std::vector<uint64_t> key(order.size());
+        {
+            // items are in group order here: the row chunk of an item = the eighth of the item list it falls in
+            const uint64_t n = order.size();
+            for (uint64_t i = 0; i < n; ++i) {
+                const uint64_t col = out.blockCols[(size_t)out.denseItems[i].first * 16];
+                uint64_t major = 0;
+                if (opt.itemOrder == 1) {
+                    // (whole groups: the chunk of the group's first item)
+                    uint64_t f = i;
+                    while (f > 0 && out.denseItems[f - 1].group == out.denseItems[i].group) --f;
+                    major = f * 8 / n;
+                } else if (opt.itemOrder == 2) {
+                    major = (col / std::max(1u, opt.orderWindow)) << 24 | out.denseItems[i].group;
+                }
+                key[i] = major << 24 | col;
+            }
+        }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
         std::vector<DenseItem> items(order.size());
         for (size_t i = 0; i < order.size(); ++i) items[i] = out.denseItems[order[i]];
         out.denseItems.swap(items);
