@@ -2374,13 +2374,14 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
 
         DeviceBuffers dev;
         const uint32_t live = liveWarpMask(T);
-        uint32_t *dRowOffsets, *dCols, *dDisp, *dSquares, *dOrder, *dCluster, *dEncOffsets = nullptr, *dEncBins = nullptr;
-        uint16_t* dEncCounts = nullptr;
+        uint32_t *dRowOffsets, *dCols, *dDisp, *dSquares, *dTotals, *dOrder, *dCluster, *dEncOffsets = nullptr, *dEncWords = nullptr;
+        uint4* dPosInfo = nullptr;
         bsmr::ClusterCount* dTable;
         bsmr::ClusterState* dState;
         if (!dev.alloc(&dRowOffsets, (size_t)rows + 1, "hipMalloc(rowOffsets)") ||
             !dev.alloc(&dCols, nnz, "hipMalloc(colIndices)") || !dev.alloc(&dTable, (size_t)rows * numBins, "hipMalloc(table)") ||
             !dev.alloc(&dDisp, rows, "hipMalloc(dispersion)") || !dev.alloc(&dSquares, rows, "hipMalloc(rowSquares)") ||
+            !dev.alloc(&dTotals, rows, "hipMalloc(rowTotals)") ||
             !dev.alloc(&dOrder, rows, "hipMalloc(order)") ||
             !dev.alloc(&dCluster, rows, "hipMalloc(cluster)") ||
             !dev.alloc(&dState, 1, "hipMalloc(state)"))
@@ -2395,7 +2396,7 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
             BSMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bsmr::clusterHistogram),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)histLds));
         hipLaunchKernelGGL(bsmr::clusterHistogram, dim3(rows), dim3(256), histLds, s, dRowOffsets, dCols,
-                           (uint32_t)numBins, bin_width, T, live, dTable, dDisp, dSquares);
+                           (uint32_t)numBins, bin_width, T, live, dTable, dDisp, dSquares, dTotals);
         BSMR_HIP(hipGetLastError());
         std::vector<uint32_t> disp(rows);
         BSMR_HIP(hipMemcpyAsync(disp.data(), dDisp, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
@@ -2405,8 +2406,7 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
         // passes first need it: two parallel sweeps over the rows (count, then fill), sorting only rows whose
         // columns are not ascending
         auto uploadSparseRows = [&]() -> int {
-            std::vector<uint32_t> encOffsets((size_t)rows + 1, 0), encBins;
-            std::vector<uint16_t> encCounts;
+            std::vector<uint32_t> encOffsets((size_t)rows + 1, 0), encWords;
             auto forRowBins = [&](uint32_t r, std::vector<uint32_t>& scratch, auto&& emit) {
                 const uint32_t b = row_offsets[r], e = row_offsets[r + 1];
                 bool ascending = true;
@@ -2434,27 +2434,23 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
                 }
             });
             for (uint32_t r = 0; r < rows; ++r) encOffsets[r + 1] += encOffsets[r];
-            encBins.resize(encOffsets[rows]);
-            encCounts.resize(encOffsets[rows]);
+            encWords.resize(encOffsets[rows]);
+            // (a bin index fits 16 bits: the histogram of a row fits in LDS, numBins <= 40 960; a count does by bin_width <= 65 535)
             bsmr::parallelChunks(rows, 1024, [&](size_t r0, size_t r1, size_t) {
                 std::vector<uint32_t> scratch;
                 for (size_t r = r0; r < r1; ++r) {
                     uint32_t at = encOffsets[r];
-                    forRowBins((uint32_t)r, scratch, [&](uint32_t bin, uint32_t count) {
-                        encBins[at] = bin;
-                        encCounts[at++] = (uint16_t)count;
-                    });
+                    forRowBins((uint32_t)r, scratch, [&](uint32_t bin, uint32_t count) { encWords[at++] = bin << 16 | count; });
                 }
             });
             if (!dev.alloc(&dEncOffsets, (size_t)rows + 1, "hipMalloc(encOffsets)") ||
-                !dev.alloc(&dEncBins, encBins.size(), "hipMalloc(encBins)") ||
-                !dev.alloc(&dEncCounts, encCounts.size(), "hipMalloc(encCounts)"))
+                !dev.alloc(&dEncWords, std::max<size_t>(1, encWords.size()), "hipMalloc(encWords)") ||
+                !dev.alloc(&dPosInfo, rows, "hipMalloc(posInfo)"))
                 return BSMR_ERR_OOM;
             BSMR_HIP(hipMemcpy(dEncOffsets, encOffsets.data(), ((size_t)rows + 1) * 4, hipMemcpyHostToDevice));
-            if (!encBins.empty()) {
-                BSMR_HIP(hipMemcpy(dEncBins, encBins.data(), encBins.size() * 4, hipMemcpyHostToDevice));
-                BSMR_HIP(hipMemcpy(dEncCounts, encCounts.data(), encCounts.size() * 2, hipMemcpyHostToDevice));
-            }
+            if (!encWords.empty()) BSMR_HIP(hipMemcpy(dEncWords, encWords.data(), encWords.size() * 4, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(bsmr::clusterPositionInfo, dim3((rows + 255) / 256), dim3(256), 0, s, dOrder, dEncOffsets, dSquares, rows, dPosInfo);
+            BSMR_HIP(hipGetLastError());
             return BSMR_OK;
         };
 
@@ -2471,55 +2467,51 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
         bsmr::ClusterState state{};
         // G workgroups per pass, each judging every G-th item of the pass; up to `active` clusters in flight
         const uint32_t grid = (uint32_t)std::max(32, std::min(envInt("BSMR_CLUSTER_GRID", 512), 65535));
-        const uint32_t maxChunk = std::max<uint32_t>(
-            bsmr::kClusterMinChunk, (uint32_t)std::min(envInt("BSMR_CLUSTER_CHUNK", (int)(8 * grid)), 1 << 24));   // (32 x grid: reddit-like shard 1 548 vs 1 367 ms; same elsewhere)
-        const uint32_t active = (uint32_t)std::max(1, std::min(envInt("BSMR_CLUSTER_ACTIVE", 16),
+        const uint32_t wantedChunk = std::max<uint32_t>(
+            bsmr::kClusterMinChunk, (uint32_t)std::min(envInt("BSMR_CLUSTER_CHUNK", (int)(32 * grid)), 1 << 24));
+        const uint32_t active = (uint32_t)std::max(1, std::min(envInt("BSMR_CLUSTER_ACTIVE", (int)bsmr::kClusterMaxActive),
                                                                (int)bsmr::kClusterMaxActive));
+        // rows with more (bin, count) entries than this are judged by a whole workgroup from the dense table
+        const uint32_t longRow = (uint32_t)std::max(64, envInt("BSMR_CLUSTER_LONG_ROW", 2048));
+        // (a workgroup of the one-wave-per-item pass lists at most 1024 items for exact evaluation)
+        const uint32_t maxChunk = std::min<uint32_t>(wantedChunk, std::max<uint32_t>(bsmr::kClusterMinChunk, 1024u * grid / active));
         if (firstNonEmpty < rows) {
             uint32_t* dReps;
             if (!dev.alloc(&dReps, (size_t)active * numBins, "hipMalloc(representatives)")) return BSMR_ERR_OOM;
-            cluster[firstNonEmpty] = 1;
-            state.numActive = 1;
-            state.nextId = 1;
-            state.floor = firstNonEmpty;
-            state.freeReps = (active >= 32 ? 0xFFFFFFFFu : (1u << active) - 1u) & ~1u;
-            state.done = firstNonEmpty + 1 >= rows ? 1u : 0u;
-            state.slot[0].seed = firstNonEmpty;
-            state.slot[0].cursor = firstNonEmpty + 1;
-            state.slot[0].chunk = 2 * bsmr::kClusterMinChunk;
-            state.slot[0].id = 1;
-            state.slot[0].firstHit = bsmr::kNoCluster;
-            state.slot[0].scan = firstNonEmpty + 1;
-            state.slot[0].rep = 0;
+            // nothing in flight: the first pass judges nothing and seeds the first clusters at scanPos
+            state.scanPos = firstNonEmpty;
+            state.tentative = (uint32_t)std::max(0, std::min(envInt("BSMR_CLUSTER_TENTATIVE", 1), (int)active));
+            state.freeReps = active >= 32 ? 0xFFFFFFFFu : (1u << active) - 1u;
             BSMR_HIP(hipMemcpyAsync(dOrder, order.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
             BSMR_HIP(hipMemcpyAsync(dCluster, cluster.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
             BSMR_HIP(hipMemcpyAsync(dState, &state, sizeof(state), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(bsmr::clusterInitRepresentative, dim3(1), dim3(T), 0, s,
-                               dTable + (size_t)order[firstNonEmpty] * numBins, dReps, (uint32_t)numBins, live, dState);
             // every pass is a no-op once `done` is set, so passes are enqueued in batches and the
             // flag is read between batches; a pass that does work advances at least one cursor
             const uint64_t passLimit = 64ull * rows + 4096;
             uint64_t enqueued = 0;
             // which form of the pass the next batch uses: the one-wave-per-item form once the passes of the last
-            // batch judged more items than there are workgroups
+            // batch judged more items than there are workgroups.  The first batches are short: what the passes of a
+            // matrix look like is not known yet, and a pass of the wrong form is slow.
             bool many = false;
             uint64_t lastWork = 0, lastPasses = 0;
+            int batch = 4;
             while (!state.done) {
                 if (enqueued > passLimit) {
                     g_lastHipError = "bsmr_cluster_rows: pass limit reached";
                     return BSMR_ERR_HIP;
                 }
-                for (int i = 0; i < 256; ++i) {
+                for (int i = 0; i < batch; ++i) {
                     if (many)
-                        hipLaunchKernelGGL(bsmr::clusterPass<true>, dim3(grid), dim3(T), 0, s, dTable, dSquares, dEncOffsets,
-                                           dEncBins, dEncCounts, dOrder, rows, (uint32_t)numBins, alpha, maxChunk, active, live,
+                        hipLaunchKernelGGL(bsmr::clusterPass<true>, dim3(grid), dim3(T), 0, s, dTable, dSquares, dTotals, dPosInfo,
+                                           dEncWords, dOrder, rows, (uint32_t)numBins, alpha, maxChunk, active, live, longRow,
                                            dReps, dCluster, dState);
                     else
-                        hipLaunchKernelGGL(bsmr::clusterPass<false>, dim3(grid), dim3(T), 0, s, dTable, dSquares, dEncOffsets,
-                                           dEncBins, dEncCounts, dOrder, rows, (uint32_t)numBins, alpha, maxChunk, active, live,
+                        hipLaunchKernelGGL(bsmr::clusterPass<false>, dim3(grid), dim3(T), 0, s, dTable, dSquares, dTotals, dPosInfo,
+                                           dEncWords, dOrder, rows, (uint32_t)numBins, alpha, maxChunk, active, live, longRow,
                                            dReps, dCluster, dState);
                 }
-                enqueued += 256;
+                enqueued += (uint64_t)batch;
+                batch = std::min(256, batch * 4);
                 BSMR_HIP(hipGetLastError());
                 BSMR_HIP(hipMemcpyAsync(&state, dState, sizeof(state), hipMemcpyDeviceToHost, s));
                 BSMR_HIP(hipStreamSynchronize(s));
@@ -2531,6 +2523,18 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
             }
             BSMR_HIP(hipMemcpyAsync(cluster.data(), dCluster, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
             BSMR_HIP(hipStreamSynchronize(s));
+            // ids count the seeds, dropped tentative ones included: dense numbering in the same order
+            std::vector<uint32_t> rank((size_t)state.nextId + 2, 0);
+            for (uint32_t p = firstNonEmpty; p < rows; ++p) {
+                if (cluster[p] == bsmr::kNoCluster || cluster[p] > state.nextId) {
+                    g_lastHipError = "bsmr_cluster_rows: a row was left without a cluster";
+                    return BSMR_ERR_HIP;
+                }
+                rank[cluster[p]] = 1;
+            }
+            uint32_t used = 0;
+            for (uint32_t id = 1; id <= state.nextId; ++id) rank[id] = rank[id] ? ++used : 0;
+            for (uint32_t p = firstNonEmpty; p < rows; ++p) cluster[p] = rank[cluster[p]];
         }
         BSMR_HIP(hipEventRecord(ev1, s));
         BSMR_HIP(hipEventSynchronize(ev1));
@@ -2560,6 +2564,8 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
             stats->exact_similarities = state.exact;
             stats->threads_per_pair = T;
             stats->table_bytes = tableBytes;
+            stats->dropped_seeds = state.dropped;
+            stats->passes_ahead = state.ahead;
         }
         return BSMR_OK;
     } catch (const std::bad_alloc&) {

@@ -11,23 +11,32 @@
 // three implementations agree bit for bit (tests/test_gpu_cluster.py).
 //
 // How it is scheduled is different.  The reference chains one single-block kernel per cluster
-// through device-side launches and per-row mutexes; gfx950 has no device-side launch.  Here:
-//   * Several clusters are in flight, oldest first.  Cluster j+1 is seeded by the first row
-//     cluster j passed over and only ever judges positions cluster j has already decided
-//     (cursor[j+1] <= cursor[j]) - the hand-over-hand order of the reference's mutexes, so every
-//     row meets the clusters in the same order and the same state as in a sequential run.
-//   * The scan of each cluster is speculative: one pass judges the next `chunk` unassigned
-//     positions of every active cluster against that cluster's representative in parallel (one
-//     workgroup per pair), the smallest accepted position of a cluster wins (atomicMin), and the
-//     last workgroup to finish merges those rows, moves each cursor behind its hit - everything
-//     before it was judged with the right representative, everything after it is judged again -
-//     adapts the chunks, retires finished clusters and seeds the next one.
+// through device-side launches and per-row mutexes; gfx950 has no device-side launch.  Here up to
+// kClusterMaxActive clusters are in flight, oldest (smallest seed) first, and every one of them runs
+// AHEAD of what is known:
+//   * A cluster is seeded TENTATIVELY at the next position that has no cluster yet, without waiting for the
+//     older clusters to pass over that position.  It is confirmed (the seed gets its id) once every older
+//     cluster's cursor is behind the seed and the seed is still free; it is dropped when an older cluster
+//     accepts its seed.  A tentative cluster has no members, so dropping it undoes nothing.  Many new
+//     clusters start in one pass (round 2 seeded one per pass: a matrix of many small clusters needed one
+//     pass per cluster at least).
+//   * The scan of each cluster is speculative: one pass judges the next `chunk` unassigned positions of every
+//     cluster against that cluster's representative in parallel, whether or not the older clusters have
+//     decided those positions.  A rejection is final as long as the representative stands.  The smallest
+//     accepted position wins (atomicMin); the last workgroup to finish closes the pass, oldest cluster first:
+//     the hit is taken if the cluster is confirmed, every older cluster's cursor is behind the position and
+//     no older cluster took the position in this pass - the row then meets the clusters in the same order and
+//     the same state as in a sequential run.  A hit that cannot be taken yet parks the cursor in front of it.
+//     Behind a hit everything is judged again with the new representative.
+//   * The representative of a cluster of one row is that row's line of the histogram table; a buffer of
+//     32-bit sums is taken at the first merge.
 //   * A similarity is only compared with alpha.  One thread forms the same quotient from the row's sparse
 //     (bin, count) list in double arithmetic - O(|row|) against O(bins) - which differs from the fp32
 //     block sum by a few 1e-6 at most; only pairs within 1e-4 of alpha are re-evaluated by the whole
 //     workgroup in the reference's exact order of operations (same rule as src/rowReordering.cpp).
-// All state lives in device memory, so the host only enqueues passes and polls a flag; a pass
-// that finds the work finished is a no-op.
+// Cluster ids count the seeds in seed order, dropped ones included: the host renumbers them densely (the order
+// is what the result depends on).  All state lives in device memory, so the host only enqueues passes and polls
+// a flag; a pass that finds the work finished is a no-op.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -42,29 +51,41 @@ typedef uint16_t ClusterCount;
 constexpr uint32_t kClusterMinChunk = 32;
 
 constexpr uint32_t kClusterMaxActive = 32;
+constexpr uint32_t kClusterSpeculateFrom = 8;
+constexpr uint32_t kClusterOwnRow = 0xFFFFFFFFu;   // ClusterSlot::rep of a cluster of one row: the seed's table line
 
 struct ClusterSlot {
-    uint32_t seed;      // position of the cluster's first row
-    uint32_t cursor;    // next position to judge
-    uint32_t chunk;     // positions judged by the next pass
-    uint32_t id;        // cluster id (1-based; 0 = empty rows)
-    uint32_t sq;        // representative's sum of squares over the bins that count (mod 2^32)
-    uint32_t total;     // representative's sum of counts over the bins that count
-    uint32_t firstHit;  // smallest accepted position of the running pass
-    uint32_t scan;      // positions in [seed + 1, scan) are assigned (search for the successor's seed)
-    uint32_t rep;       // which representative buffer the cluster owns
+    uint32_t seed;       // position of the cluster's first row
+    uint32_t cursor;     // next position to judge: everything in (seed, cursor) is assigned or was rejected
+    uint32_t chunk;      // positions judged by the next pass
+    uint32_t id;         // cluster id (1-based, in seed order; 0 = empty rows)
+    uint32_t sq;         // representative's sum of squares over the bins that count (mod 2^32)
+    uint32_t total;      // representative's sum of counts over the bins that count
+    uint32_t firstHit;   // smallest accepted position of the running pass
+    uint32_t rep;        // which representative buffer the cluster owns, kClusterOwnRow before the first merge
+    uint32_t confirmed;  // every older cluster has passed over the seed
+    uint32_t seedRow;    // the seed's row id (its table line is the representative before the first merge)
+    uint32_t len, start; // the next pass judges `len` unassigned positions from `cursor` on; they are items [start, start + len) of
+                         // the pass (set by the workgroup that closes a pass, for the next one)
+    uint32_t parked;     // the row at `cursor` was accepted, but an older cluster has not decided it yet: nothing is judged
+                         // until it has (the representative does not change meanwhile, so the verdict stands)
 };
 
 struct ClusterState {
     uint32_t numActive;  // slots [0, numActive), oldest first
-    uint32_t nextId;     // id of the youngest cluster
-    uint32_t floor;      // every position below is assigned
+    uint32_t nextId;     // id of the youngest seed
+    uint32_t scanPos;    // every position below is assigned or is the seed of a slot
     uint32_t freeReps;   // bit r = representative buffer r is free
     uint32_t arrived;    // workgroups of the running pass that have finished
     uint32_t done;       // every row has a cluster
     uint32_t passes;     // statistics
     uint32_t judged;     // statistics: similarities decided by the O(|row|) evaluation
     uint32_t exact;      // statistics: similarities that needed the exact block-order evaluation
+    uint32_t dropped;    // statistics: tentative clusters whose seed an older cluster accepted
+    uint32_t tentative;  // how many clusters may run unconfirmed at a time: one more after a pass in which seeds were confirmed,
+                         // half (down to none: only seeds that are certain) after a pass in which one was dropped
+    uint32_t ahead;      // statistics: passes in which the clusters ran ahead of the older ones' decisions
+    uint32_t startChunk; // first chunk of a new cluster: running mean of the chunks finished clusters ended with
     ClusterSlot slot[kClusterMaxActive];
 };
 
@@ -79,9 +100,9 @@ __device__ __forceinline__ bool binCounts(uint32_t b, uint32_t T, uint32_t liveW
 __global__ void clusterHistogram(const uint32_t* __restrict__ rowOffsets, const uint32_t* __restrict__ colIndices,
                                  uint32_t numBins, uint32_t binWidth, uint32_t T, uint32_t liveWarps,
                                  ClusterCount* __restrict__ table, uint32_t* __restrict__ dispersion,
-                                 uint32_t* __restrict__ rowSquares) {
+                                 uint32_t* __restrict__ rowSquares, uint32_t* __restrict__ rowTotals) {
     extern __shared__ uint32_t hist[];
-    __shared__ uint32_t partial[3];
+    __shared__ uint32_t partial[4];
     const uint32_t row = blockIdx.x;
     const uint32_t b = rowOffsets[row], e = rowOffsets[row + 1];
     ClusterCount* out = table + (size_t)row * numBins;
@@ -89,31 +110,37 @@ __global__ void clusterHistogram(const uint32_t* __restrict__ rowOffsets, const 
         if (threadIdx.x == 0) {
             dispersion[row] = 0;
             rowSquares[row] = 0;
+            rowTotals[row] = 0;
         }
         return;  // the table was zeroed
     }
     for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) hist[i] = 0;
-    if (threadIdx.x < 3) partial[threadIdx.x] = 0;
+    if (threadIdx.x < 4) partial[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) atomicAdd(&hist[colIndices[i] / binWidth], 1u);
     __syncthreads();
-    uint32_t touched = 0, slack = 0, squares = 0;
+    uint32_t touched = 0, slack = 0, squares = 0, counted = 0;
     for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
         const uint32_t v = hist[i];
         out[i] = (ClusterCount)v;
         if (v) {
             ++touched;
             slack += binWidth - v;
-            if (binCounts(i, T, liveWarps)) squares += v * v;
+            if (binCounts(i, T, liveWarps)) {
+                squares += v * v;
+                counted += v;
+            }
         }
     }
     atomicAdd(&partial[0], touched);
     atomicAdd(&partial[1], slack);
     atomicAdd(&partial[2], squares);
+    atomicAdd(&partial[3], counted);
     __syncthreads();
     if (threadIdx.x == 0) {
         dispersion[row] = partial[1] + (e - b) * partial[0];
         rowSquares[row] = partial[2];
+        rowTotals[row] = partial[3];
     }
 }
 
@@ -144,7 +171,8 @@ __device__ __forceinline__ void blockSumAsReference(float& a, float& b, float* s
 
 // src/rowReordering.cu:235-293.  The two sums of squares are integers: their masked values are
 // kept per row (clusterHistogram) and per representative (ClusterState::sqRep).
-__device__ __forceinline__ float similarityAsReference(const uint32_t* __restrict__ rep, uint32_t sqRep,
+template <typename RepT>
+__device__ __forceinline__ float similarityAsReference(const RepT* __restrict__ rep, uint32_t sqRep,
                                                        const ClusterCount* __restrict__ cmp, uint32_t sqCmp,
                                                        uint32_t numBins, float* shmA, float* shmB) {
     if (sqRep == 0 && sqCmp == 0) return 1.0f;
@@ -165,40 +193,55 @@ __device__ __forceinline__ float similarityAsReference(const uint32_t* __restric
 // One speculative pass (see the header comment).  The positions to judge of all active clusters form one
 // list; thread t of workgroup g takes items g*T + t, g*T + t + G*T, ... (G = gridDim.x, T = blockDim.x) and
 // skips an item once an earlier position of the same cluster has been accepted.
+// what the one-wave-per-item form needs to know about the row at a position, in one load: where its sparse (bin, count)
+// list lies, its sum of squares, its id
+__global__ void clusterPositionInfo(const uint32_t* __restrict__ order, const uint32_t* __restrict__ encOffsets,
+                                    const uint32_t* __restrict__ rowSquares, uint32_t rows, uint4* __restrict__ posInfo) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= rows) return;
+    const uint32_t row = order[p];
+    posInfo[p] = uint4{encOffsets[row], encOffsets[row + 1], rowSquares[row], row};
+}
+
+// posInfo / encWords: MANY only.  encWords[i] = bin << 16 | count of the i-th nonzero bin (bins ascending inside a row).
 template <bool MANY>
-__global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__ rowSquares,
-                            const uint32_t* __restrict__ encOffsets, const uint32_t* __restrict__ encBins,
-                            const uint16_t* __restrict__ encCounts, const uint32_t* __restrict__ order, uint32_t rows,
-                            uint32_t numBins, float alpha, uint32_t maxChunk, uint32_t maxActive, uint32_t liveWarps,
-                            uint32_t* __restrict__ reps, uint32_t* __restrict__ cluster,
-                            ClusterState* __restrict__ state) {
+__global__ void __launch_bounds__(1024, MANY ? 8 : 4)
+clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__ rowSquares,
+                            const uint32_t* __restrict__ rowTotals, const uint4* __restrict__ posInfo,
+                            const uint32_t* __restrict__ encWords,
+                            const uint32_t* __restrict__ order, uint32_t rows, uint32_t numBins, float alpha,
+                            uint32_t maxChunk, uint32_t maxActive, uint32_t liveWarps, uint32_t longRow, uint32_t* __restrict__ reps,
+                            uint32_t* __restrict__ cluster, ClusterState* __restrict__ state) {
     __shared__ float shmA[32], shmB[32];
-    __shared__ uint32_t shared[3];
+    __shared__ uint32_t shared[4];
     __shared__ uint32_t sCursor[kClusterMaxActive], sLen[kClusterMaxActive], sStart[kClusterMaxActive + 1];
     __shared__ uint32_t sHit[kClusterMaxActive], sSumSq[kClusterMaxActive], sSumTotal[kClusterMaxActive];
-    __shared__ ClusterSlot sSlot[kClusterMaxActive + 1];
+    __shared__ uint32_t sAccept[kClusterMaxActive], sNew[kClusterMaxActive];
+    __shared__ uint8_t sDrop[kClusterMaxActive], sFirstMerge[kClusterMaxActive];
+    __shared__ unsigned long long sBallot[16];
+    __shared__ ClusterSlot sSlot[kClusterMaxActive];
     // MANY only: items of this round within 1e-4 of alpha, (cluster << 27) | offset in its window
     __shared__ uint32_t sNear[MANY ? 1024 : 1];
     __shared__ uint32_t sNearCount;
     if (state->done) return;  // uniform over the grid: the state only changes at the end of a pass
     const uint32_t active = state->numActive;
     const uint32_t T = blockDim.x;
-    if (threadIdx.x < active) sSlot[threadIdx.x] = state->slot[threadIdx.x];  // one slot per lane: one round trip
-    __syncthreads();
+    // (what the closing workgroup needs of the state is read here, together with the rest: it changes at the end of a pass only)
+    const uint32_t tentativeIn = state->tentative, scanPosIn = state->scanPos, nextIdIn = state->nextId;
+    const uint32_t freeRepsIn = state->freeReps, startChunkIn = state->startChunk;
+    const uint32_t passesIn = state->passes, aheadIn = state->ahead, droppedIn = state->dropped;
+    const bool speculate = tentativeIn >= kClusterSpeculateFrom;
+    if (threadIdx.x < active) {  // one slot per lane: one round trip
+        const ClusterSlot c = state->slot[threadIdx.x];
+        sSlot[threadIdx.x] = c;
+        sCursor[threadIdx.x] = c.cursor;
+        sLen[threadIdx.x] = c.len;
+        sStart[threadIdx.x] = c.start;
+        if (threadIdx.x + 1 == active) sStart[active] = c.start + c.len;
+    }
     if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (uint32_t j = 0; j < active; ++j) {
-            const ClusterSlot& c = sSlot[j];
-            // a younger cluster only judges what the next older one has already decided
-            const uint32_t limit = j == 0 ? rows : sSlot[j - 1].cursor;
-            const uint32_t len = c.cursor < limit ? (c.chunk < limit - c.cursor ? c.chunk : limit - c.cursor) : 0u;
-            sCursor[j] = c.cursor;
-            sLen[j] = len;
-            sStart[j] = total;
-            total += len;
-        }
-        sStart[active] = total;
         sNearCount = 0;
+        if (active == 0) sStart[0] = 0;
     }
     __syncthreads();
     const uint32_t total = sStart[active];
@@ -210,9 +253,18 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
     // items per pass, latency counts - every item is evaluated exactly by a whole workgroup straight from the
     // dense table (two dependent loads instead of four, a small kernel).  MANY = true: throughput counts -
     // one wave per item decides from the sparse list, the workgroup only re-evaluates the near ones.
-    const uint32_t wgsWithWork = MANY ? (total + wavesPerWG - 1) / wavesPerWG : total;
+    uint32_t wgsWithWork = total;
+    if (wgsWithWork == 0) wgsWithWork = 1;  // nothing to judge (no cluster in flight): workgroup 0 still closes the pass
     if (blockIdx.x >= wgsWithWork) return;  // nothing to judge, and nobody waits for this workgroup
     const uint32_t participants = wgsWithWork < gridDim.x ? wgsWithWork : gridDim.x;
+    // the representative of cluster j, as one of two types
+    auto ownRow = [&](uint32_t j) { return table + (size_t)sSlot[j].seedRow * numBins; };
+    auto exactSimilarity = [&](uint32_t j, uint32_t row) {
+        const ClusterCount* cmp = table + (size_t)row * numBins;
+        return sSlot[j].rep == kClusterOwnRow
+                   ? similarityAsReference(ownRow(j), sSlot[j].sq, cmp, rowSquares[row], numBins, shmA, shmB)
+                   : similarityAsReference(reps + (size_t)sSlot[j].rep * numBins, sSlot[j].sq, cmp, rowSquares[row], numBins, shmA, shmB);
+    };
     uint32_t judged = 0, exact = 0;
     if constexpr (!MANY) {
         for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
@@ -228,87 +280,120 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
                 if (best < pos) continue;
             }
             if (cluster[pos] != kNoCluster) continue;
-            const uint32_t row = order[pos];
-            const float sim = similarityAsReference(reps + (size_t)sSlot[j].rep * numBins, sSlot[j].sq,
-                                                    table + (size_t)row * numBins, rowSquares[row], numBins, shmA, shmB);
+            const float sim = exactSimilarity(j, order[pos]);
             ++exact;
             if (threadIdx.x == 0 && sim > alpha) atomicMin(&state->slot[j].firstHit, pos);
         }
     }
-    for (uint32_t base = blockIdx.x * wavesPerWG; MANY && base < total; base += gridDim.x * wavesPerWG) {  // uniform
+    // neighbouring items go to different workgroups: the rows with long lists sit next to each other in the dispersion order
+    // (a workgroup per cluster window with the representative in LDS was tried: 780 against 590 ms on the reddit-like
+    // shard - the pass waits for its slowest workgroup, and the gathers are not what it is bound by)
+    // What is known about an item before its row's list can be read - which cluster, the smallest accepted position so far,
+    // whether the position is taken, where the list lies - is fetched one item ahead: three loads that depend on nothing
+    // but the item's number, issued together, in flight while the item before is judged.
+    auto locate = [&](uint32_t item, uint32_t& j, uint32_t& pos) {
+        uint32_t lo = 0, hi = active;   // the cluster whose window holds the item: sStart[lo] <= item < sStart[lo + 1]
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (item >= sStart[mid]) lo = mid;
+            else hi = mid;
+        }
+        j = lo;
+        pos = sCursor[lo] + (item - sStart[lo]);
+    };
+    uint32_t nextJ = 0, nextPos = 0, nextBest = 0, nextCluster = 0;
+    uint4 nextInfo = {0, 0, 0, 0};
+    auto fetch = [&](uint32_t item) {
+        locate(item, nextJ, nextPos);
+        // (a plain load of firstHit: it may see an old value out of the CU's L1, which only prunes less)
+        nextBest = state->slot[nextJ].firstHit;
+        nextCluster = cluster[nextPos];
+        nextInfo = posInfo[nextPos];
+    };
+    const uint32_t itemStride = gridDim.x * wavesPerWG;
+    if (MANY && blockIdx.x + gridDim.x * wave < total) fetch(blockIdx.x + gridDim.x * wave);
+    for (uint32_t item = blockIdx.x + gridDim.x * wave; MANY && item < total; item += itemStride) {  // per wave
         // -- decided from the row's sparse histogram unless it is close to alpha --
-        const uint32_t item = base + wave;
-        if (item < total) {
-            uint32_t j = 0;
-            while (item >= sStart[j + 1]) ++j;
-            const uint32_t pos = sCursor[j] + (item - sStart[j]);
-            const uint32_t best = __hip_atomic_load(&state->slot[j].firstHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (pos < best && cluster[pos] == kNoCluster) {  // (wave-uniform up to the race on firstHit, which only prunes)
-                const uint32_t row = order[pos];
-                const uint32_t sqRep = sSlot[j].sq, sqRow = rowSquares[row];
-                if (lane == 0) ++judged;
-                bool hit = false, near = false;
-                if (sqRep == 0 || sqRow == 0) {  // src/rowReordering.cu:263-268
-                    hit = (sqRep == 0 && sqRow == 0 ? 1.0f : 0.0f) > alpha;
-                } else {
-                    const uint32_t* rep = reps + (size_t)sSlot[j].rep * numBins;
-                    const double normRep = (double)sqrtf((float)sqRep), normRow = (double)sqrtf((float)sqRow);
-                    // min + max = x + y in every bin, so  sum max = |x|_1 + |y|_1 - sum min: only the min-sum and the
-                    // row's own |y|_1 are accumulated, with reciprocals instead of two divisions per bin (the value is
-                    // only compared with alpha, and anything within 1e-4 of it is evaluated exactly below)
-                    const double invRep = 1.0 / normRep, invRow = 1.0 / normRow;
-                    double minSum = 0.0, sumY = 0.0;
-                    // eight entries per lane at a time: their (bin, count) loads are issued together, then the eight
-                    // gathers from the representative - a lane's chain is two round trips per batch instead of two per
-                    // entry (a pass of this form was bound by exactly that chain: 67 us median on the reddit-like shard)
-                    const uint32_t rowEnd = encOffsets[row + 1];
-                    for (uint32_t i0 = encOffsets[row] + lane; i0 < rowEnd; i0 += 8u * lanes) {
-                        uint32_t bins[8], counts[8], repCounts[8];
+        const uint32_t j = nextJ, pos = nextPos, best = nextBest, taken = nextCluster;
+        const uint4 info = nextInfo;
+        if (item + itemStride < total) fetch(item + itemStride);
+        if (pos < best && taken == kNoCluster) {  // (wave-uniform up to the race on firstHit, which only prunes)
+            const uint32_t sqRep = sSlot[j].sq, sqRow = info.z;
+            if (lane == 0) ++judged;
+            bool hit = false, near = false;
+            if (sqRep == 0 || sqRow == 0) {  // src/rowReordering.cu:263-268
+                hit = (sqRep == 0 && sqRow == 0 ? 1.0f : 0.0f) > alpha;
+            } else if (info.y - info.x > longRow) {
+                // a long list keeps one wave busy for many round trips while the pass waits for it: the whole
+                // workgroup evaluates it from the dense table instead (O(bins / T) per thread)
+                near = true;
+            } else {
+                const bool own = sSlot[j].rep == kClusterOwnRow;
+                const uint32_t* rep32 = reps + (size_t)(own ? 0u : sSlot[j].rep) * numBins;
+                const ClusterCount* rep16 = own ? ownRow(j) : table;
+                const double normRep = (double)sqrtf((float)sqRep), normRow = (double)sqrtf((float)sqRow);
+                // min + max = x + y in every bin, so  sum max = |x|_1 + |y|_1 - sum min: only the min-sum and the
+                // row's own |y|_1 are accumulated, with reciprocals instead of two divisions per bin (the value is
+                // only compared with alpha, and anything within 1e-4 of it is evaluated exactly below)
+                const double invRep = 1.0 / normRep, invRow = 1.0 / normRow;
+                double minSum = 0.0, sumY = 0.0;
+                // (every bin counts when the reference's fold skips no warp, i.e. T / 32 is a power of two: no modulo then)
+                const bool allLive = (uint32_t)__popc(liveWarps) == (T + 31u) / 32u;
+                // eight entries per lane at a time: their words are loaded together, then the eight gathers from
+                // the representative are issued together - a lane's chain is two round trips per batch instead of
+                // two per entry
+                const uint32_t rowEnd = info.y;
+                for (uint32_t i0 = info.x + lane; i0 < rowEnd; i0 += 8u * lanes) {
+                    uint32_t words[8], repCounts[8];
 #pragma unroll
-                        for (uint32_t u = 0; u < 8; ++u) {
-                            const uint32_t i = i0 + u * lanes;
-                            const bool ok = i < rowEnd;
-                            bins[u] = ok ? encBins[i] : 0xFFFFFFFFu;
-                            counts[u] = ok ? (uint32_t)encCounts[i] : 0u;
-                        }
-#pragma unroll
-                        for (uint32_t u = 0; u < 8; ++u) repCounts[u] = bins[u] != 0xFFFFFFFFu ? rep[bins[u]] : 0u;
-#pragma unroll
-                        for (uint32_t u = 0; u < 8; ++u) {
-                            if (bins[u] == 0xFFFFFFFFu || !binCounts(bins[u], T, liveWarps)) continue;
-                            const double x = (double)repCounts[u] * invRep, y = (double)counts[u] * invRow;
-                            minSum += x < y ? x : y;
-                            sumY += y;
-                        }
+                    for (uint32_t u = 0; u < 8; ++u) {
+                        const uint32_t i = i0 + u * lanes;
+                        words[u] = i < rowEnd ? encWords[i] : 0xFFFFFFFFu;
                     }
-                    for (uint32_t w = lanes >> 1; w >= 1; w >>= 1) {
-                        minSum += __shfl_xor(minSum, w, 64);
-                        sumY += __shfl_xor(sumY, w, 64);
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; ++u)
+                        repCounts[u] = words[u] != 0xFFFFFFFFu ? (own ? (uint32_t)rep16[words[u] >> 16] : rep32[words[u] >> 16]) : 0u;
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; ++u) {
+                        if (words[u] == 0xFFFFFFFFu || !(allLive || binCounts(words[u] >> 16, T, liveWarps))) continue;
+                        const double x = (double)repCounts[u] * invRep, y = (double)(words[u] & 0xFFFFu) * invRow;
+                        minSum += x < y ? x : y;
+                        sumY += y;
                     }
-                    const double approx = minSum / ((double)sSlot[j].total * invRep + sumY - minSum);
-                    const double margin = approx - (double)alpha;
-                    if (margin > 1e-4) hit = true;
-                    else if (margin >= -1e-4) near = true;
                 }
-                if (lane == 0) {
-                    if (hit) atomicMin(&state->slot[j].firstHit, pos);
-                    if (near) sNear[atomicAdd(&sNearCount, 1u)] = (j << 27) | (item - sStart[j]);
+                for (uint32_t w = lanes >> 1; w >= 1; w >>= 1) {
+                    minSum += __shfl_xor(minSum, w, 64);
+                    sumY += __shfl_xor(sumY, w, 64);
                 }
+                const double approx = minSum / ((double)sSlot[j].total * invRep + sumY - minSum);
+                const double margin = approx - (double)alpha;
+                if (margin > 1e-4) hit = true;
+                else if (margin >= -1e-4) near = true;
+            }
+            if (lane == 0) {
+                if (hit) atomicMin(&state->slot[j].firstHit, pos);
+                if (near) sNear[atomicAdd(&sNearCount, 1u)] = (j << 27) | (item - sStart[j]);
             }
         }
+    }
+    if constexpr (MANY) {
+        // -- the near ones again, by the whole workgroup, in the reference's order of operations (after all rounds:
+        //    the waves run through their items without waiting for each other; a workgroup has at most
+        //    kClusterMaxActive * maxChunk / gridDim.x <= 1024 items, the host sees to that) --
         __syncthreads();
-        // -- the near ones again, by the whole workgroup, in the reference's order of operations --
         const uint32_t nearCount = sNearCount;
         for (uint32_t n = 0; n < nearCount; ++n) {
             const uint32_t j = sNear[n] >> 27, pos = sCursor[j] + (sNear[n] & 0x07FFFFFFu);
-            const uint32_t row = order[pos];
-            const float sim = similarityAsReference(reps + (size_t)sSlot[j].rep * numBins, sSlot[j].sq,
-                                                    table + (size_t)row * numBins, rowSquares[row], numBins, shmA, shmB);
+            if (threadIdx.x == 0)
+                shared[2] = __hip_atomic_load(&state->slot[j].firstHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const uint32_t best = shared[2];
+            __syncthreads();
+            if (best < pos) continue;  // behind an accepted position: judged again by a later pass
+            const float sim = exactSimilarity(j, order[pos]);
             if (threadIdx.x == 0 && sim > alpha) atomicMin(&state->slot[j].firstHit, pos);
+            ++exact;
         }
-        exact += nearCount;
-        __syncthreads();
-        if (threadIdx.x == 0) sNearCount = 0;
         __syncthreads();
     }
     // the last workgroup to arrive closes the pass
@@ -328,69 +413,168 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
     if (!shared[0]) return;
     __threadfence();
 
-    uint32_t sTotal = 0;
-    // rep = first (assign) or rep += first (merge); returns the new sum of squares over the bins
-    // that count (UIN arithmetic: wraps).  Every thread only touches the bins it owns.
-    // Also leaves the new sum of counts over those bins in shared[2].
-    auto absorb = [&](uint32_t* __restrict__ rep, const ClusterCount* __restrict__ first, bool merge) {
-        if (threadIdx.x == 0) shared[1] = shared[2] = 0;
-        __syncthreads();
-        uint32_t sq = 0, tot = 0;
-        for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
-            const uint32_t v = merge ? rep[i] + (uint32_t)first[i] : (uint32_t)first[i];
-            rep[i] = v;
-            if (binCounts(i, blockDim.x, liveWarps)) {
-                sq += v * v;
-                tot += v;
-            }
-        }
-        for (uint32_t w = lanes >> 1; w >= 1; w >>= 1) {
-            sq += __shfl_xor(sq, w, 64);
-            tot += __shfl_xor(tot, w, 64);
-        }
-        if ((threadIdx.x & 63u) == 0) {
-            atomicAdd(&shared[1], sq);
-            atomicAdd(&shared[2], tot);
-        }
-        __syncthreads();
-        const uint32_t sum = shared[1];
-        sTotal = shared[2];
-        __syncthreads();
-        return sum;
-    };
-    // smallest unassigned position in [from, to), kNoCluster if there is none
-    auto firstUnassigned = [&](uint32_t from, uint32_t to) {
-        if (threadIdx.x == 0) shared[1] = kNoCluster;
-        __syncthreads();
-        uint32_t found = kNoCluster;
-        for (uint32_t base = from; base < to; base += blockDim.x) {
-            const uint32_t p = base + threadIdx.x;
-            if (p < to && cluster[p] == kNoCluster) atomicMin(&shared[1], p);
-            __syncthreads();
-            found = shared[1];
-            __syncthreads();  // nobody updates the slot for the next stretch before everyone has read it
-            if (found != kNoCluster) break;
-        }
-        return found;
-    };
-
-    // 1. hits: every accepted row is merged into its cluster's representative.  The clusters are
-    //    independent here, so all merges run in one sweep (per-cluster sums: a wave adds its lanes up
-    //    and issues one LDS atomic), followed by the scalar bookkeeping of thread 0.
+    // 1. decisions, oldest cluster first.  Lane j of the first wave holds cluster j; the loop over the clusters reads the
+    //    one it is at with v_readlane, so nothing but registers is touched (a single thread walking the slots in LDS
+    //    cost more than everything else in a pass of few items).
     if (threadIdx.x < active) {
         sHit[threadIdx.x] = __hip_atomic_load(&state->slot[threadIdx.x].firstHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sSumSq[threadIdx.x] = 0;
         sSumTotal[threadIdx.x] = 0;
+        // a parked cluster's verdict on the row in front of it stands; has somebody else taken that row meanwhile?
+        sNew[threadIdx.x] = 0;
+        if (sSlot[threadIdx.x].parked) {
+            const uint32_t at = sSlot[threadIdx.x].cursor;
+            sHit[threadIdx.x] = at;
+            sNew[threadIdx.x] = __hip_atomic_load(&cluster[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kNoCluster;
+        }
     }
     __syncthreads();
+    if (threadIdx.x < 32u) {
+        const uint32_t j = threadIdx.x;
+        const bool mine = j < active;
+        ClusterSlot c = sSlot[mine ? j : 0u];
+        const uint32_t myHit = mine ? sHit[j] : kNoCluster, myLen = mine ? sLen[j] : 0u, myStart = mine ? sCursor[j] : 0u;
+        const uint32_t myAssigned = mine ? sNew[j] : 0u;
+        // which older clusters accepted (in this pass) the row I accepted / my seed?
+        uint32_t sameHit = 0, seedHit = 0;
+        for (uint32_t i = 0; i < active; ++i) {
+            const uint32_t h = __builtin_amdgcn_readlane(myHit, i);
+            if (i < j && h != kNoCluster) {
+                if (h == myHit) sameHit |= 1u << i;
+                if (h == c.seed) seedHit |= 1u << i;
+            }
+        }
+        // A confirmed cluster without a hit moves on by itself.  The others are walked in order, oldest first: what an
+        // older cluster decides (its new cursor, the row it takes) bears on the younger ones.
+        const bool walked = mine && (myHit != kNoCluster || !c.confirmed);
+        if (mine && !walked && myLen) {
+            c.cursor = myStart + myLen;
+            if (myLen == c.chunk) c.chunk = 4u * c.chunk > maxChunk ? maxChunk : 4u * c.chunk;
+        }
+        // smallest cursor among the older clusters that are not walked (exclusive prefix minimum over the lanes)
+        uint32_t olderMin = mine && !walked ? c.cursor : 0xFFFFFFFFu;
+        for (uint32_t w = 1; w < 32u; w <<= 1) {
+            const uint32_t other = __shfl_up(olderMin, w, 32);
+            if (j >= w) olderMin = olderMin < other ? olderMin : other;
+        }
+        olderMin = __shfl_up(olderMin, 1, 32);
+        if (j == 0) olderMin = 0xFFFFFFFFu;
+        uint32_t walkedMin = rows, freeReps = freeRepsIn, dropped = 0, accepted = 0;   // uniform over the lanes
+        uint32_t myAccept = kNoCluster, myDrop = 0, myFirstMerge = 0, myConfirmNow = 0;
+        for (uint32_t todo = (uint32_t)__ballot(walked); todo; todo &= todo - 1u) {
+            const uint32_t k = (uint32_t)__builtin_ctz(todo);
+            const uint32_t older = __builtin_amdgcn_readlane(olderMin, k);
+            const uint32_t decided = older < walkedMin ? older : walkedMin;   // every older cluster's cursor is at least here
+            const uint32_t seed = __builtin_amdgcn_readlane(c.seed, k), hit = __builtin_amdgcn_readlane(myHit, k);
+            const uint32_t start = __builtin_amdgcn_readlane(myStart, k), len = __builtin_amdgcn_readlane(myLen, k);
+            const uint32_t parked = __builtin_amdgcn_readlane(c.parked, k), assigned = __builtin_amdgcn_readlane(myAssigned, k);
+            const uint32_t hitTaken = __builtin_amdgcn_readlane(sameHit, k) & accepted, seedTaken = __builtin_amdgcn_readlane(seedHit, k) & accepted;
+            uint32_t confirmed = __builtin_amdgcn_readlane(c.confirmed, k), cursor = __builtin_amdgcn_readlane(c.cursor, k);
+            uint32_t chunk = __builtin_amdgcn_readlane(c.chunk, k), rep = __builtin_amdgcn_readlane(c.rep, k);
+            uint32_t nowParked = parked, accept = kNoCluster, drop = 0, firstMerge = 0, confirmNow = 0;
+            if (!confirmed) {
+                if (seedTaken) {
+                    drop = 1;
+                    ++dropped;
+                } else if (decided > seed) {
+                    confirmed = 1;
+                    confirmNow = 1;
+                }
+            }
+            if (!drop) {
+                if (hit != kNoCluster) {
+                    // judging costs time even beside the hit, so the next pass looks twice as far as this hit was
+                    if (!parked) {
+                        const uint32_t gap = 2u * (hit - start + 1u);
+                        chunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
+                    }
+                    if (hitTaken || (parked && assigned)) {  // somebody older has it
+                        cursor = hit + 1;
+                        nowParked = 0;
+                    } else if (confirmed && hit < decided) {  // every older cluster has passed over it
+                        nowParked = 0;
+                        accept = hit;
+                        accepted |= 1u << k;
+                        cursor = hit + 1;
+                        if (rep == kClusterOwnRow) {
+                            rep = (uint32_t)__builtin_ctz(freeReps);
+                            freeReps &= freeReps - 1u;
+                            firstMerge = 1;
+                        }
+                    } else {  // an older cluster has not decided that position yet: wait in front of it
+                        cursor = hit;
+                        nowParked = 1;
+                    }
+                } else if (len) {
+                    // (a tentative cluster looks no further per pass than it did at first: what it judges may be for nothing)
+                    cursor = start + len;
+                    if (len == chunk && confirmed) chunk = 4u * chunk > maxChunk ? maxChunk : 4u * chunk;
+                }
+                walkedMin = walkedMin < cursor ? walkedMin : cursor;
+            }
+            if (j == k) {
+                c.confirmed = confirmed;
+                c.cursor = cursor;
+                c.chunk = chunk;
+                c.rep = rep;
+                c.parked = nowParked;
+                myAccept = accept;
+                myDrop = drop;
+                myFirstMerge = firstMerge;
+                myConfirmNow = confirmNow;
+            }
+        }
+        c.firstHit = kNoCluster;
+        // 2. dropped and finished clusters leave (a tentative cluster that has judged everything waits for its confirmation)
+        const bool finished = mine && !myDrop && c.confirmed && c.cursor >= rows;
+        const bool keep = mine && !myDrop && !finished;
+        const uint32_t keepMask = (uint32_t)__ballot(keep), finishedMask = (uint32_t)__ballot(finished);
+        const uint32_t slotNow = __popc(keepMask & ((1u << j) - 1u));
+        if (mine) {
+            sAccept[j] = myAccept;
+            sFirstMerge[j] = (uint8_t)myFirstMerge;
+            sDrop[j] = (uint8_t)(keep ? slotNow : 0xFFu);   // where the slot goes (0xFF: nowhere)
+            if (myConfirmNow && !myDrop) cluster[c.seed] = c.id;
+            if (myAccept != kNoCluster) {
+                cluster[myAccept] = c.id;
+                sNew[j] = order[myAccept];   // the row to merge (all of them fetched at once)
+            }
+            sSlot[j] = c;   // (moved to its place after the merges, which read rep and seedRow by the old index)
+        }
+        // the first chunk of the next clusters: running mean over the finished ones (any order)
+        uint32_t startChunk = startChunkIn, minCursor = keep ? c.cursor : rows;
+        for (uint32_t f = finishedMask; f; f &= f - 1u) {
+            const uint32_t k = (uint32_t)__builtin_ctz(f);
+            startChunk = (3u * startChunk + __builtin_amdgcn_readlane(c.chunk, k)) / 4u;
+            const uint32_t r = __builtin_amdgcn_readlane(c.rep, k);
+            if (r != kClusterOwnRow) freeReps |= 1u << r;
+        }
+        for (uint32_t w = 16; w >= 1; w >>= 1) {
+            const uint32_t other = __shfl_xor(minCursor, w, 32);
+            minCursor = minCursor < other ? minCursor : other;
+        }
+        if (j == 0) {
+            shared[0] = __popc(keepMask);
+            shared[1] = freeReps;
+            shared[2] = dropped;
+            shared[3] = minCursor;
+            sStart[0] = __popc((uint32_t)__ballot(keep && !c.confirmed));   // (the item list is not needed any more)
+            sStart[1] = __popc((uint32_t)__ballot(mine && myConfirmNow && !myDrop));
+            sStart[2] = startChunk < 2u * kClusterMinChunk ? 2u * kClusterMinChunk : (startChunk > maxChunk ? maxChunk : startChunk);
+        }
+    }
+    __syncthreads();
+    // 3. merges: every accepted row is added to its cluster's representative.  The clusters are independent
+    //    here, so all merges run in one sweep (per-cluster sums: a wave adds its lanes up and issues one LDS atomic)
     for (uint32_t j = 0; j < active; ++j) {
-        const uint32_t hit = sHit[j];
+        const uint32_t hit = sAccept[j];
         if (hit == kNoCluster) continue;  // uniform
         uint32_t* rep = reps + (size_t)sSlot[j].rep * numBins;
-        const ClusterCount* add = table + (size_t)order[hit] * numBins;
+        const ClusterCount* add = table + (size_t)sNew[j] * numBins;
+        const ClusterCount* own = sFirstMerge[j] ? ownRow(j) : nullptr;
         uint32_t sq = 0, tot = 0;
         for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
-            const uint32_t v = rep[i] + (uint32_t)add[i];
+            const uint32_t v = (own ? (uint32_t)own[i] : rep[i]) + (uint32_t)add[i];
             rep[i] = v;
             if (binCounts(i, blockDim.x, liveWarps)) {
                 sq += v * v;
@@ -407,115 +591,133 @@ __global__ void clusterPass(const ClusterCount* __restrict__ table, const uint32
         }
     }
     __syncthreads();
-    if (threadIdx.x < active) {
-        const uint32_t j = threadIdx.x, hit = sHit[j];
-        const uint32_t cursor = sCursor[j], len = sLen[j], chunk = sSlot[j].chunk;
-        if (hit != kNoCluster) {
-            cluster[hit] = sSlot[j].id;
-            sSlot[j].sq = sSumSq[j];
-            sSlot[j].total = sSumTotal[j];
-            sSlot[j].cursor = hit + 1;
-            // judging costs time even beside the hit, so the next pass looks twice as far as this hit was
-            const uint32_t gap = 2u * (hit - cursor + 1u);
-            sSlot[j].chunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
-        } else if (len) {
-            sSlot[j].cursor = cursor + len;
-            if (len == chunk) sSlot[j].chunk = 4u * chunk > maxChunk ? maxChunk : 4u * chunk;  // not held back by the older one
-        }
-        sSlot[j].firstHit = kNoCluster;
-    }
-    __syncthreads();
-    // 2. retire finished clusters (only the oldest can be finished: the others trail it)
-    uint32_t retired = 0, floor = state->floor, freeReps = state->freeReps, nextId = state->nextId;
-    while (retired < active && sSlot[retired].cursor >= rows) {
-        freeReps |= 1u << sSlot[retired].rep;
-        if (sSlot[retired].seed + 1 > floor) floor = sSlot[retired].seed + 1;
-        ++retired;
-    }
-    uint32_t left = active - retired;
-    __syncthreads();
-    if (retired) {
-        if (threadIdx.x == 0)
-            for (uint32_t j = 0; j < left; ++j) sSlot[j] = sSlot[j + retired];
-        __syncthreads();
-    }
-    // 3. the successor of the youngest cluster starts at the first row that cluster passed over;
-    //    with nothing in flight, at the first row that has no cluster at all
-    uint32_t done = 0;
-    if (left < maxActive) {
-        uint32_t from, to;
-        if (left) {
-            from = sSlot[left - 1].scan;
-            to = sSlot[left - 1].cursor < rows ? sSlot[left - 1].cursor : rows;
-        } else {
-            from = floor;
-            to = rows;
-        }
-        const uint32_t found = firstUnassigned(from, to);
-        if (found == kNoCluster) {
-            if (left == 0) done = 1;
-            else if (threadIdx.x == 0 && to > from) sSlot[left - 1].scan = to;  // all of that stretch is assigned
-        } else {
-            uint32_t r = 0;
-            while (!((freeReps >> r) & 1u)) ++r;
-            freeReps &= ~(1u << r);
-            ++nextId;
-            const uint32_t sq = absorb(reps + (size_t)r * numBins, table + (size_t)order[found] * numBins, false);
-            if (threadIdx.x == 0) {
-                cluster[found] = nextId;
-                if (left) sSlot[left - 1].scan = found + 1;
-                ClusterSlot c;
-                c.seed = found;
-                c.cursor = found + 1;
-                c.chunk = 2u * kClusterMinChunk;
-                c.id = nextId;
-                c.sq = sq;
-                c.total = sTotal;
-                c.firstHit = kNoCluster;
-                c.scan = found + 1;
-                c.rep = r;
-                sSlot[left] = c;
+    {
+        ClusterSlot c;
+        const bool moves = threadIdx.x < active && sDrop[threadIdx.x] != 0xFFu;
+        if (moves) {
+            c = sSlot[threadIdx.x];
+            if (sAccept[threadIdx.x] != kNoCluster) {
+                c.sq = sSumSq[threadIdx.x];
+                c.total = sSumTotal[threadIdx.x];
             }
-            // seeded by the very last position with nothing else in flight: that cluster is complete
-            if (left == 0 && found + 1 >= rows) done = 1;
-            ++left;
         }
         __syncthreads();
+        if (moves) sSlot[sDrop[threadIdx.x]] = c;
+    }
+    __syncthreads();
+    uint32_t left = shared[0];
+    const uint32_t freeReps = shared[1], dropped = shared[2], minCursor = shared[3];
+    const uint32_t unconfirmed = sStart[0], confirmedNow = sStart[1], startChunk = sStart[2];
+    uint32_t tentative = tentativeIn;
+    __syncthreads();
+    // 4. new clusters: the next positions without a cluster, in order.  The first of them is a cluster for certain when
+    //    everything in flight has passed over it (round 2 seeded only those); beyond it, as many as may run unconfirmed.
+    uint32_t scanPos = scanPosIn, numNew = 0;
+    const uint32_t room = left < maxActive ? maxActive - left : 0u;
+    const uint32_t allowed = tentative > unconfirmed ? tentative - unconfirmed : 0u;
+    // (with no tentative cluster allowed, only a position everything in flight has passed over can become a seed)
+    const uint32_t cap = allowed == 0 && minCursor <= scanPos ? 0u : (room < allowed + 1u ? room : allowed + 1u);   // candidates to look for
+    __threadfence();  // (the assignments of step 1 are read back here)
+    for (uint32_t round = 0; round < 8u && numNew < cap && scanPos < rows; ++round) {  // uniform
+        const uint32_t p = scanPos + threadIdx.x;
+        const bool isFree = p < rows && __hip_atomic_load(&cluster[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kNoCluster;
+        const unsigned long long mask = __ballot(isFree);
+        if (lane == 0) sBallot[wave] = mask;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t n = numNew;
+            for (uint32_t w = 0; w < wavesPerWG && n < cap; ++w) {
+                unsigned long long m = sBallot[w];
+                while (m && n < cap) {
+                    const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    sNew[n++] = scanPos + 64u * w + bit;
+                }
+            }
+            shared[0] = n;
+            shared[1] = n == cap ? sNew[n - 1] + 1u : (scanPos + T < rows ? scanPos + T : rows);
+        }
+        __syncthreads();
+        numNew = shared[0];
+        scanPos = shared[1];
+        __syncthreads();
+    }
+    uint32_t certain = 0;
+    if (numNew) {  // uniform
+        certain = minCursor > sNew[0] ? 1u : 0u;
+        uint32_t take = allowed + certain < room ? allowed + certain : room;
+        if (take < numNew) {  // the candidates not taken are found again by a later pass
+            scanPos = sNew[take];
+            numNew = take;
+        }
+    }
+    const uint32_t nextId = nextIdIn;
+    if (numNew == 0) certain = 0;
+    // a dropped cluster halves the number that may run unconfirmed; a pass whose seeds held adds one
+    if (dropped) tentative >>= 1;
+    else if ((confirmedNow || certain) && tentative < maxActive) ++tentative;
+    if (threadIdx.x < numNew) {
+        const uint32_t u = sNew[threadIdx.x], row = order[u];
+        ClusterSlot c;
+        c.seed = u;
+        c.seedRow = row;
+        c.cursor = u + 1;
+        c.chunk = startChunk;
+        c.id = nextId + 1u + threadIdx.x;
+        c.sq = rowSquares[row];
+        c.total = rowTotals[row];
+        c.firstHit = kNoCluster;
+        c.rep = kClusterOwnRow;
+        c.parked = 0;
+        c.confirmed = threadIdx.x == 0 && certain ? 1u : 0u;
+        if (c.confirmed) cluster[u] = c.id;
+        sSlot[left + threadIdx.x] = c;
+    }
+    left += numNew;
+    __syncthreads();
+    // 5. what the next pass judges.  Running ahead of the older clusters pays when most rows end up in clusters of their
+    //    own (what a younger cluster judges early is then rarely taken away by an older one) and costs when clusters are
+    //    large.  The number of clusters that may run unconfirmed measures exactly that; below kClusterSpeculateFrom a
+    //    cluster only judges what every older one has decided (round 2's rule: all it accepts can be taken at once, nothing
+    //    is judged for nothing).
+    if (threadIdx.x < 32u) {
+        const uint32_t j = threadIdx.x;
+        const bool mine = j < left;
+        const uint32_t cursor = mine ? sSlot[j].cursor : 0xFFFFFFFFu, chunk = mine ? sSlot[j].chunk : 0u;
+        const bool parked = mine && sSlot[j].parked;
+        uint32_t olderMin = cursor;   // exclusive prefix minimum of the cursors
+        for (uint32_t w = 1; w < 32u; w <<= 1) {
+            const uint32_t other = __shfl_up(olderMin, w, 32);
+            if (j >= w) olderMin = olderMin < other ? olderMin : other;
+        }
+        olderMin = __shfl_up(olderMin, 1, 32);
+        uint32_t limit = rows;
+        if (tentative < kClusterSpeculateFrom && j > 0 && olderMin < limit) limit = olderMin;
+        const uint32_t len = mine && cursor < limit && !parked ? (chunk < limit - cursor ? chunk : limit - cursor) : 0u;
+        uint32_t upTo = len;          // inclusive prefix sum of the lengths
+        for (uint32_t w = 1; w < 32u; w <<= 1) {
+            const uint32_t other = __shfl_up(upTo, w, 32);
+            if (j >= w) upTo += other;
+        }
+        if (mine) {
+            sSlot[j].len = len;
+            sSlot[j].start = upTo - len;
+        }
     }
     __syncthreads();
     if (threadIdx.x < left) state->slot[threadIdx.x] = sSlot[threadIdx.x];
     if (threadIdx.x == 0) {
         state->numActive = left;
-        state->nextId = nextId;
-        state->floor = floor;
+        state->nextId = nextId + numNew;
+        state->scanPos = scanPos;
         state->freeReps = freeReps;
         state->arrived = 0;
-        state->passes += 1;
-        state->done = done;
-    }
-}
-
-// first representative = the seed row's histogram; its sum of squares as in clusterPass
-__global__ void clusterInitRepresentative(const ClusterCount* __restrict__ seedRow, uint32_t* __restrict__ rep,
-                                          uint32_t numBins, uint32_t liveWarps, ClusterState* __restrict__ state) {
-    __shared__ uint32_t total[2];
-    if (threadIdx.x < 2) total[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t sq = 0, tot = 0;
-    for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
-        const uint32_t v = seedRow[i];
-        rep[i] = v;
-        if (binCounts(i, blockDim.x, liveWarps)) {
-            sq += v * v;
-            tot += v;
-        }
-    }
-    atomicAdd(&total[0], sq);
-    atomicAdd(&total[1], tot);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        state->slot[0].sq = total[0];
-        state->slot[0].total = total[1];
+        state->passes = passesIn + 1;
+        state->ahead = aheadIn + (speculate ? 1u : 0u);
+        state->dropped = droppedIn + dropped;
+        state->tentative = tentative;
+        state->startChunk = startChunk;
+        state->done = left == 0 && scanPos >= rows ? 1u : 0u;
     }
 }
 

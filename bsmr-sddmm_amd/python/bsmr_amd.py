@@ -94,7 +94,8 @@ class ReorderingReport(C.Structure):
 
 class ClusterStats(C.Structure):
     _fields_ = [("elapsed_ms", C.c_float), ("passes", C.c_uint32), ("similarities", C.c_uint32),
-                ("exact_similarities", C.c_uint32), ("threads_per_pair", C.c_uint32), ("table_bytes", C.c_uint64)]
+                ("exact_similarities", C.c_uint32), ("threads_per_pair", C.c_uint32), ("table_bytes", C.c_uint64),
+                ("dropped_seeds", C.c_uint32), ("passes_ahead", C.c_uint32)]
 
 
 class ColReorderSizes(C.Structure):

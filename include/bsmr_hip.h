@@ -278,6 +278,8 @@ typedef struct bsmr_cluster_stats {
     uint32_t exact_similarities;/* ... of which within 1e-4 of alpha (exact evaluation) */
     uint32_t threads_per_pair;  /* workgroup size = the reference's clustering block  */
     uint64_t table_bytes;       /* rows x bins histogram table                        */
+    uint32_t dropped_seeds;     /* clusters started ahead of the older ones' decisions whose seed an older one took */
+    uint32_t passes_ahead;      /* passes in which clusters judged rows the older clusters had not decided yet    */
 } bsmr_cluster_stats;
 int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const uint32_t *row_offsets,
                       const uint32_t *col_indices, uint32_t bin_width, float alpha,

@@ -1,14 +1,16 @@
 #!/bin/bash
-# GPU box: kernel statistics of the device row clustering on the reddit-like shard (rocprofv3 --kernel-trace --stats).
+# GPU box: kernel statistics of the device row clustering (rocprofv3 --kernel-trace --stats).
+# usage: tools/cluster_trace.sh [reddit|myc15]
 set -o pipefail
+WHAT=${1:-reddit}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/cluster_trace
+OUT=$ROOT/gpurun_out/cluster_trace_$WHAT
 rm -rf $OUT && mkdir -p $OUT
-cat > $OUT/run.py <<'PY'
+cat > $OUT/run.py <<PY
 import sys
 sys.path.insert(0, "bsmr-sddmm_amd/python")
 import bsmr_amd as eng, synth
-rows, cols, ro, ci = synth.reddit_shard_like()
+rows, cols, ro, ci = synth.reddit_shard_like() if "$WHAT" == "reddit" else synth.mycielskian_pattern(15)
 csr = eng.CSR.from_arrays(rows, cols, ro, ci)
 bw = eng.host().bsmr_calculate_block_size(csr.handle, 200 << 30)
 st, perm, clusters, stats = eng.cluster_rows_device(rows, cols, ro, ci, bw, 0.3)
