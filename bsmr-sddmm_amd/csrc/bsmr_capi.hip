@@ -159,6 +159,17 @@ struct bsmr_plan {
     bool overlap = false;
     hipStream_t sideStream = nullptr;
     hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
+
+    // options.k_hint > 0: the RPHM arrays are kept so that bsmr_plan_tune can build this plan under other plan-time rules
+    // (promotion of the residue, folding of a small dense part) and time the variants; every call on the plan is served by
+    // `delegate` when a variant won
+    struct Retained {
+        bsmr_rphm_desc desc{};
+        std::vector<uint32_t> reorderedRows, denseCols, blockOffsets, blockValues, sparseOffsets, sparseValues, sparseRows, sparseCols;
+    };
+    std::unique_ptr<Retained> retained;
+    bsmr_plan* delegate = nullptr;
+    int variantChosen = 0;         // BSMR_VARIANT_* of the plan that serves the calls
 };
 
 namespace {
@@ -169,6 +180,8 @@ namespace {
 constexpr uint64_t kGroupedGatherBytes = 400ull << 20;
 
 thread_local std::string g_lastHipError;
+inline bsmr_plan* served(bsmr_plan* p) { return p && p->delegate ? p->delegate : p; }
+inline const bsmr_plan* served(const bsmr_plan* p) { return p && p->delegate ? p->delegate : p; }
 // Where a launch goes: the stream and, for a batched call, the strides between the problems of the batch (grid y).
 struct Queue {
     hipStream_t stream = nullptr;
@@ -1500,6 +1513,7 @@ int bsmr_plan_options_default(bsmr_plan_options* opt) {
     o.sweep_fp32 = -1;
     o.sweep_waves = 0;
     o.sweep_per_cu = 0;
+    o.k_hint = 0;
     *opt = o;
     return BSMR_OK;
 }
@@ -1527,7 +1541,7 @@ int bsmr_plan_options_from_env(bsmr_plan_options* opt) {
         {"BSMR_B_ONLY_WORK_M", &o.b_only_work_m}, {"BSMR_OVERLAP_STREAMS", &o.overlap_streams},
         {"BSMR_MASK_TILES", &o.mask_tiles}, {"BSMR_PACK_ON_DEVICE", &o.pack_on_device},
         {"BSMR_SWEEP_PANELS", &o.sweep_panels}, {"BSMR_SWEEP_BLOCKS", &o.sweep_strip_blocks}, {"BSMR_SWEEP_FP32", &o.sweep_fp32},
-        {"BSMR_SWEEP_WAVES", &o.sweep_waves}, {"BSMR_SWEEP_PER_CU", &o.sweep_per_cu},
+        {"BSMR_SWEEP_WAVES", &o.sweep_waves}, {"BSMR_SWEEP_PER_CU", &o.sweep_per_cu}, {"BSMR_K_HINT", &o.k_hint},
     };
     for (const auto& k : knobs) *k.field = envInt(k.name, *k.field);
     return BSMR_OK;
@@ -1542,6 +1556,7 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
 int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_plan_options* options) {
     if (!out || !d) return BSMR_ERR_INVALID_ARG;
     *out = nullptr;
+    const bsmr_rphm_desc* const given = d;
     bsmr_plan_options o;
     bsmr_plan_options_default(&o);
     if (options) {   // a caller built against an older header passes a shorter struct: the rest keeps its defaults
@@ -1825,6 +1840,32 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         }
         p->buildMs[3] = msSince(tSecond);
         p->buildMs[4] = msSince(tStart);
+        if (o.k_hint > 0) {   // (the caller's arrays, not the promoted / folded ones the plan was packed from)
+            const bsmr_rphm_desc& src = *given;
+            auto keep = std::make_unique<bsmr_plan::Retained>();
+            const uint64_t blocks = src.block_offsets[P], sparse = src.sparse_value_offsets[P];
+            auto copy = [](std::vector<uint32_t>& to, const uint32_t* from, uint64_t n) {
+                if (from && n) to.assign(from, from + n);
+            };
+            copy(keep->reorderedRows, src.reordered_rows, src.num_nonzero_rows);
+            copy(keep->denseCols, src.dense_cols, blocks * 16);
+            copy(keep->blockOffsets, src.block_offsets, (uint64_t)P + 1);
+            copy(keep->blockValues, src.block_values, blocks * 256);
+            copy(keep->sparseOffsets, src.sparse_value_offsets, (uint64_t)P + 1);
+            copy(keep->sparseValues, src.sparse_values, sparse);
+            copy(keep->sparseRows, src.sparse_relative_rows, sparse);
+            copy(keep->sparseCols, src.sparse_col_indices, sparse);
+            keep->desc = src;
+            keep->desc.reordered_rows = keep->reorderedRows.data();
+            keep->desc.dense_cols = keep->denseCols.data();
+            keep->desc.block_offsets = keep->blockOffsets.data();
+            keep->desc.block_values = keep->blockValues.data();
+            keep->desc.sparse_value_offsets = keep->sparseOffsets.data();
+            keep->desc.sparse_values = keep->sparseValues.data();
+            keep->desc.sparse_relative_rows = keep->sparseRows.data();
+            keep->desc.sparse_col_indices = keep->sparseCols.data();
+            p->retained = std::move(keep);
+        }
         *out = p;
         return BSMR_OK;
     } catch (const std::bad_alloc&) {
@@ -1836,6 +1877,10 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
 
 int bsmr_plan_destroy(bsmr_plan* plan) {
     if (!plan) return BSMR_OK;
+    if (plan->delegate) {
+        bsmr_plan_destroy(plan->delegate);
+        plan->delegate = nullptr;
+    }
     if (hipSetDevice(plan->device) != hipSuccess) (void)hipGetLastError();
     freePlanDevice(plan);
     delete plan;
@@ -1843,6 +1888,7 @@ int bsmr_plan_destroy(bsmr_plan* plan) {
 }
 
 int bsmr_plan_format_digest(const bsmr_plan* p, uint64_t out[13]) {
+    p = served(p);
     if (!p || !out) return BSMR_ERR_INVALID_ARG;
     BSMR_HIP(hipSetDevice(p->device));
     const DenseFormat& f = p->fmt[0];
@@ -1880,6 +1926,7 @@ int bsmr_plan_format_digest(const bsmr_plan* p, uint64_t out[13]) {
 }
 
 int bsmr_plan_build_times(const bsmr_plan* p, bsmr_plan_build_ms* out) {
+    p = served(p);
     if (!p || !out) return BSMR_ERR_INVALID_ARG;
     out->rules_ms = p->buildMs[0];
     out->pack_ms = p->buildMs[1];
@@ -1890,6 +1937,7 @@ int bsmr_plan_build_times(const bsmr_plan* p, bsmr_plan_build_ms* out) {
 }
 
 int bsmr_plan_get_stats(const bsmr_plan* p, bsmr_plan_stats* out) {
+    p = served(p);
     if (!p || !out) return BSMR_ERR_INVALID_ARG;
     const DenseFormat& f = p->fmt[0];
     out->num_row_panels = p->numPanels;
@@ -1914,6 +1962,7 @@ int bsmr_plan_get_stats(const bsmr_plan* p, bsmr_plan_stats* out) {
 
 int bsmr_plan_dense_choice(const bsmr_plan* plan, uint32_t K, uint32_t* group_size, uint64_t* tiles,
                            uint64_t* union_columns) {
+    plan = served(plan);
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (sweepEngine(plan)) {   // (of the call prepared last) rows and columns of K elements streamed: every item its panels and its strip
         const SweepFormatDev& w = plan->sweeps[(size_t)plan->sweepNow];
@@ -1940,6 +1989,7 @@ int bsmr_plan_dense_choice(const bsmr_plan* plan, uint32_t K, uint32_t* group_si
 
 int bsmr_plan_sparse_choice(const bsmr_plan* plan, uint32_t K, int mode, uint32_t* lanes_per_entry,
                             uint32_t* low_precision) {
+    plan = served(plan);
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     const bool lowp = mode != BSMR_COMPUTE_F32 && plan->sparseLowp && plan->numSparseItems &&
@@ -1950,6 +2000,7 @@ int bsmr_plan_sparse_choice(const bsmr_plan* plan, uint32_t K, int mode, uint32_
 }
 
 int bsmr_plan_dense_flags(const bsmr_plan* plan, uint8_t* flags_host) {
+    plan = served(plan);
     if (!plan || (!flags_host && plan->nnz)) return BSMR_ERR_INVALID_ARG;
     BSMR_HIP(hipSetDevice(plan->device));
     std::fill(flags_host, flags_host + plan->nnz, (uint8_t)1);
@@ -1962,6 +2013,7 @@ int bsmr_plan_dense_flags(const bsmr_plan* plan, uint8_t* flags_host) {
 }
 
 int bsmr_plan_reserve(bsmr_plan* plan, uint32_t K) {
+    plan = served(plan);
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     BSMR_HIP(hipSetDevice(plan->device));
@@ -1972,6 +2024,7 @@ int bsmr_plan_reserve(bsmr_plan* plan, uint32_t K) {
 
 int bsmr_sddmm(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode,
                void* stream) {
+    plan = served(plan);
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     BSMR_HIP(hipSetDevice(plan->device));
@@ -1982,6 +2035,7 @@ int bsmr_sddmm(bsmr_plan* plan, uint32_t K, const float* A, const float* B, floa
 
 int bsmr_sddmm_batch(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, uint32_t num_batches,
                      int mode, void* stream) {
+    plan = served(plan);
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     if (num_batches == 0) return BSMR_OK;
@@ -2014,6 +2068,7 @@ int bsmr_batched_transpose(uint32_t width, uint32_t height, uint32_t num_batches
 
 int bsmr_convert_operands(bsmr_plan* plan, uint32_t K, const float* A, const float* B, void* A16,
                           void* B16, int mode, void* stream) {
+    plan = served(plan);
     if (!plan || !A || !B || !A16 || !B16) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     if (mode != BSMR_COMPUTE_F16 && mode != BSMR_COMPUTE_BF16) return BSMR_ERR_INVALID_ARG;
@@ -2026,6 +2081,7 @@ int bsmr_convert_operands(bsmr_plan* plan, uint32_t K, const float* A, const flo
 
 int bsmr_sddmm_lowp(bsmr_plan* plan, uint32_t K, const void* A16, const void* B16, const float* A,
                     const float* B, float* P, int mode, void* stream) {
+    plan = served(plan);
     if (!plan || !A16 || !B16 || !P) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     if (mode != BSMR_COMPUTE_F16 && mode != BSMR_COMPUTE_BF16) return BSMR_ERR_INVALID_ARG;
@@ -2049,6 +2105,7 @@ int bsmr_sddmm_lowp(bsmr_plan* plan, uint32_t K, const void* A16, const void* B1
 
 int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode,
                      void* stream, int warmup, int iters, bsmr_timing* out) {
+    plan = served(plan);
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     if (!out || iters <= 0 || warmup < 0) return BSMR_ERR_INVALID_ARG;
@@ -2086,8 +2143,9 @@ int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B
     return st;
 }
 
-int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode, void* stream,
-                   bsmr_tune_report* report) {
+namespace {
+int tuneEngines(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode, void* stream,
+                bsmr_tune_report* report) {
     constexpr float kTuneMargin = 0.98f;   // what the untuned rules choose stays unless an alternative is 2 % faster
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
@@ -2276,8 +2334,119 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
     return st;
 }
 
+// whole calls of the plan as it is (its tuned choices included), microseconds per call
+int timeWholeCalls(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode, hipStream_t s, float* us) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    BSMR_HIP(hipEventCreate(&e0));
+    if (!hipOk(hipEventCreate(&e1), "hipEventCreate")) {
+        (void)hipEventDestroy(e0);
+        return BSMR_ERR_HIP;
+    }
+    int st = BSMR_OK;
+    float best = 1e30f;
+    for (int rep = 0; rep < 3 && st == BSMR_OK; ++rep) {
+        const int iters = 30;
+        for (int i = 0; i < 3 && st == BSMR_OK; ++i) st = bsmr_sddmm(plan, K, A, B, P, mode, s);
+        if (st != BSMR_OK) break;
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters && st == BSMR_OK; ++i) st = bsmr_sddmm(plan, K, A, B, P, mode, s);
+        (void)hipEventRecord(e1, s);
+        if (!hipOk(hipEventSynchronize(e1), "hipEventSynchronize")) st = BSMR_ERR_HIP;
+        float ms = 0.f;
+        if (st == BSMR_OK && hipOk(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime")) best = std::min(best, ms * 1000.f / iters);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *us = best;
+    return st;
+}
+}  // namespace
+
+int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode, void* stream,
+                   bsmr_tune_report* report) {
+    if (!plan) return BSMR_ERR_INVALID_ARG;
+    bsmr_tune_report r{};
+    if (!plan->retained) {   // no hint: the engines of the plan as it was built
+        const int st = tuneEngines(served(plan), K, A, B, P, mode, stream, &r);
+        r.chosen_variant = plan->variantChosen;
+        for (float& v : r.variant_us) v = -1.f;
+        if (st == BSMR_OK && report) *report = r;
+        return st;
+    }
+    // The plan-time rules as variants: each is a plan of its own, tuned like the first, timed over whole calls.
+    constexpr float kVariantMargin = 0.97f;   // the rules' plan stays unless a variant is 3 % faster
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (plan->delegate) {   // (tuned before, maybe for another K: start over from the plan itself)
+        bsmr_plan_destroy(plan->delegate);
+        plan->delegate = nullptr;
+        plan->variantChosen = BSMR_VARIANT_RULES;
+    }
+    int st = tuneEngines(plan, K, A, B, P, mode, stream, &r);
+    if (st != BSMR_OK) return st;
+    float variantUs[6] = {-1.f, -1.f, -1.f, -1.f, -1.f, -1.f};
+    if ((st = timeWholeCalls(plan, K, A, B, P, mode, s, &variantUs[0])) != BSMR_OK) return st;
+    struct Split {
+        uint64_t blocks, dense, sparse;
+        bool operator==(const Split& o) const { return blocks == o.blocks && dense == o.dense && sparse == o.sparse; }
+    };
+    auto splitOf = [](const bsmr_plan* p) { return Split{p->fmt[0].numBlocks, p->numDenseEntries, p->numSparseEntries}; };
+    std::vector<Split> seen{splitOf(plan)};
+    bsmr_plan* best = nullptr;
+    float bestUs = variantUs[0] * kVariantMargin;
+    int bestVariant = BSMR_VARIANT_RULES;
+    bsmr_tune_report bestReport = r;
+    for (int v = BSMR_VARIANT_AS_RPHM; v <= BSMR_VARIANT_ALL_RESIDUE; ++v) {
+        bsmr_plan_options o = plan->opt;
+        o.k_hint = 0;
+        switch (v) {
+            case BSMR_VARIANT_AS_RPHM: o.promote_average = 0; o.promote_head = 0; o.fold_dense_below = 0; break;
+            case BSMR_VARIANT_NO_PROMOTION: o.promote_average = 0; o.promote_head = 0; break;
+            case BSMR_VARIANT_PROMOTE_24: o.promote_average = 24; break;
+            case BSMR_VARIANT_PROMOTE_ALL: o.promote_average = 1; o.promote_min_entries_k = 0; o.promote_column_degree = 0; break;
+            default: o.promote_average = 0; o.promote_head = 0; o.fold_dense_below = 0x7FFFFFFF; break;
+        }
+        bsmr_plan* alt = nullptr;
+        if ((st = bsmr_plan_create_ex(&alt, plan->device, &plan->retained->desc, &o)) != BSMR_OK) break;
+        const Split split = splitOf(alt);
+        if (std::find(seen.begin(), seen.end(), split) != seen.end()) {   // the same work as a plan already timed
+            bsmr_plan_destroy(alt);
+            continue;
+        }
+        seen.push_back(split);
+        bsmr_tune_report altReport{};
+        if ((st = tuneEngines(alt, K, A, B, P, mode, stream, &altReport)) == BSMR_OK)
+            st = timeWholeCalls(alt, K, A, B, P, mode, s, &variantUs[v]);
+        if (st != BSMR_OK) {
+            bsmr_plan_destroy(alt);
+            break;
+        }
+        if (variantUs[v] < bestUs) {
+            if (best) bsmr_plan_destroy(best);
+            best = alt;
+            bestUs = variantUs[v];
+            bestVariant = v;
+            bestReport = altReport;
+        } else {
+            bsmr_plan_destroy(alt);
+        }
+    }
+    if (st != BSMR_OK) {
+        if (best) bsmr_plan_destroy(best);
+        return st;
+    }
+    plan->delegate = best;
+    plan->variantChosen = bestVariant;
+    bestReport.chosen_variant = bestVariant;
+    std::copy(variantUs, variantUs + 6, bestReport.variant_us);
+    // leave a complete result of the serving plan in P
+    st = bsmr_sddmm(plan, K, A, B, P, mode, stream);
+    if (st == BSMR_OK && report) *report = bestReport;
+    return st;
+}
+
 int bsmr_sddmm_host(bsmr_plan* plan, uint32_t K, const float* A_host, const float* B_host, float* P_host,
                     int mode, int iters, float* ms_per_iter) {
+    plan = served(plan);
     int st = checkCall(plan, K, A_host, B_host, P_host, mode);
     if (st != BSMR_OK) return st;
     if (iters <= 0) iters = 1;

@@ -43,6 +43,10 @@ class RphmDesc(C.Structure):
                 ("sparse_relative_rows", u32p), ("sparse_col_indices", u32p)]
 
 
+# BSMR_VARIANT_* (include/bsmr_hip.h): the plan-time rules bsmr_plan_tune tries for a plan created with k_hint > 0
+VARIANT_NAMES = ("rules", "as_rphm", "no_promotion", "promote_24", "promote_all", "all_residue")
+
+
 class TuneReport(C.Structure):
     _fields_ = [("chosen_engine", C.c_int32), ("chosen_group", C.c_int32), ("chosen_blocks_per_item", C.c_int32),
                 ("stream_us", C.c_float), ("grouped_us", C.c_float), ("tiles_us", C.c_float), ("shared_us", C.c_float),
@@ -50,7 +54,7 @@ class TuneReport(C.Structure):
                 ("chosen_overlap", C.c_int32), ("one_stream_us", C.c_float), ("two_streams_us", C.c_float),
                 ("chosen_cvt_in_kernel", C.c_int32), ("convert_pass_us", C.c_float), ("fp32_dense_us", C.c_float),
                 ("sweep_us", C.c_float), ("lowp_call_us", C.c_float), ("sweep_fp32_call_us", C.c_float),
-                ("chosen_sweep_fp32", C.c_int32)]
+                ("chosen_sweep_fp32", C.c_int32), ("chosen_variant", C.c_int32), ("variant_us", C.c_float * 6)]
 
 
 class PlanBuildMs(C.Structure):
@@ -77,7 +81,7 @@ class PlanOptions(C.Structure):
         "column_order", "dense_stream", "dense_batch", "tile_group", "tile_blocks_per_item", "tile_depth",
         "sparse_entries_per_item", "sparse_lowp", "sparse_lpe", "free_residue", "convert_in_kernel", "convert_sliced",
         "b_only", "b_only_work_m", "overlap_streams", "mask_tiles", "pack_on_device", "sweep_panels", "sweep_strip_blocks",
-        "sweep_fp32", "sweep_waves", "sweep_per_cu")]
+        "sweep_fp32", "sweep_waves", "sweep_per_cu", "k_hint")]
 
 
 ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED, ENGINE_TUNED, ENGINE_SWEEP = 0, 1, 2, 3, 4
@@ -510,6 +514,8 @@ def plan_tune(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, mode=COMPUTE_F16
         out[name] = round(getattr(r, name), 2)
     out["b_only"], out["overlap"], out["cvt_in_kernel"] = r.chosen_b_only, r.chosen_overlap, r.chosen_cvt_in_kernel
     out["sweep_fp32"] = r.chosen_sweep_fp32
+    out["variant"] = VARIANT_NAMES[r.chosen_variant]
+    out["variant_us"] = {VARIANT_NAMES[i]: round(r.variant_us[i], 2) for i in range(6) if r.variant_us[i] >= 0}
     return out
 
 

@@ -196,6 +196,11 @@ typedef struct bsmr_plan_options {
     int32_t  sweep_waves;           /* consumer waves per workgroup: 0 = 4; 4, 8                                [SWEEP_WAVES] */
     int32_t  sweep_per_cu;          /* workgroups per CU the LDS ring is sized for: 0 = 1; 1, 2 (2: four consumer waves only)
                                                                                                               [SWEEP_PER_CU] */
+    int32_t  k_hint;                /* 0 (default): the plan-time rules above (promotion of the residue, folding of a small
+                                       dense part) are thresholds fitted once, K unknown.  > 0: the inner dimension the plan
+                                       will mostly be called with - the plan keeps a copy of the RPHM arrays, and
+                                       bsmr_plan_tune builds it under the other settings of those rules too
+                                       (BSMR_VARIANT_*), times whole calls and lets the fastest serve the plan  [K_HINT] */
 } bsmr_plan_options;
 int bsmr_plan_options_default(bsmr_plan_options *opt);
 /* defaults, then every BSMR_<NAME> variable that is set */
@@ -249,7 +254,17 @@ typedef struct bsmr_tune_report {
     float   sweep_us;
     float   lowp_call_us, sweep_fp32_call_us;
     int32_t chosen_sweep_fp32;        /* 1: the chosen engine is the sweep kernel on fp32 operands */
+    /* plans created with k_hint > 0 (appended): whole-call time of the plan under each setting of the plan-time rules,
+     * microseconds (< 0: not built - the same split as an earlier variant, or no hint), and the one that serves the plan */
+    int32_t chosen_variant;           /* BSMR_VARIANT_* */
+    float   variant_us[6];
 } bsmr_tune_report;
+#define BSMR_VARIANT_RULES        0   /* the options the plan was created with                                    */
+#define BSMR_VARIANT_AS_RPHM      1   /* the RPHM's split as it is: nothing promoted, nothing folded              */
+#define BSMR_VARIANT_NO_PROMOTION 2   /* promote_average = 0                                                      */
+#define BSMR_VARIANT_PROMOTE_24   3   /* promote_average = 24                                                     */
+#define BSMR_VARIANT_PROMOTE_ALL  4   /* every panel's residue becomes blocks                                     */
+#define BSMR_VARIANT_ALL_RESIDUE  5   /* the dense part folded into the residue                                   */
 int bsmr_plan_tune(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev, float *P_dev, int mode, void *stream,
                    bsmr_tune_report *report /* may be NULL */);
 

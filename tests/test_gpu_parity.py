@@ -881,6 +881,54 @@ def test_tuned_plans_measure_the_dense_engines(engine, oracle):
     engine.plan_destroy(plain)
 
 
+def test_k_hint_lets_the_tuner_time_the_plan_time_rules(engine, oracle):
+    """bsmr_plan_options.k_hint > 0: bsmr_plan_tune builds the plan under the other settings of the promotion / folding
+    rules too (BSMR_VARIANT_*), times whole calls and lets the fastest serve the plan.  Results stay the oracle's whichever
+    serves; the served variant is the fastest measured (3 % margin for the rules); without a hint nothing changes."""
+    dev = _dev()
+    for name, (r, c, ro, ci), delta in (
+            ("hybrid community graph", synth.community_graph(n=4096, avg_degree=64, communities=8, seed=5), 0.2),
+            ("small dense part", synth.nips_like(rows=400, cols=3000, nnz=30000, seed=2), 0.3)):
+        csr = engine.CSR.from_arrays(r, c, ro, ci)
+        arrays = engine.Pipeline(csr, alpha=0.3, delta=delta, device=-1).arrays()
+        for K in (32, 128):
+            A, B = engine.make_data(r * K, 5489), engine.make_data(c * K, 5490)
+            want = oracle.sddmm_cpu(r, c, K, ro, ci, A, B)
+            tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+            tP = torch.full((csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+            st, plan = engine.plan_from_arrays(r, c, csr.nnz, arrays, device=0,
+                                               options=engine.plan_options(dense_engine=engine.ENGINE_TUNED, k_hint=K))
+            assert st == engine.OK
+            stats0 = engine.PlanStats()
+            engine.hip().bsmr_plan_get_stats(plan, stats0)
+            report = engine.plan_tune(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
+            torch.cuda.synchronize()
+            print(f"{name} K={K}: {report['variant']} {report['variant_us']}")
+            times = report["variant_us"]
+            assert "rules" in times and len(times) >= 2, times
+            assert times[report["variant"]] <= min(times.values()) * 1.0001 or report["variant"] == "rules"
+            if report["variant"] == "rules":
+                assert min(times.values()) >= times["rules"] * 0.97 - 1e-3
+            stats1 = engine.PlanStats()
+            engine.hip().bsmr_plan_get_stats(plan, stats1)      # the statistics are the serving plan's
+            assert stats1.num_dense_entries + stats1.num_sparse_entries == csr.nnz
+            if report["variant"] == "rules":
+                assert (stats1.num_dense_entries, stats1.num_sparse_entries) == (stats0.num_dense_entries, stats0.num_sparse_entries)
+            for label in ("left by tune", "served"):
+                bad, first = oracle.check_data(want, tP.cpu().numpy())
+                assert bad == 0, (name, K, label, bad, first)
+                tP.fill_(float("nan"))
+                engine.sddmm(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
+                torch.cuda.synchronize()
+            engine.plan_destroy(plan)
+    # no hint: the report says so and the plan is what the rules built
+    st, plan = engine.plan_from_arrays(r, c, csr.nnz, arrays, device=0, options=engine.plan_options(dense_engine=engine.ENGINE_TUNED))
+    assert st == engine.OK
+    report = engine.plan_tune(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
+    assert report["variant"] == "rules" and report["variant_us"] == {}
+    engine.plan_destroy(plan)
+
+
 @pytest.mark.shipping_rules
 @pytest.mark.parametrize("K", [32, 64, 128])
 @pytest.mark.parametrize("mask_tiles", [0, 1])

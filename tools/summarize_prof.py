@@ -37,7 +37,7 @@ out = {"bench": {k: bench[k] for k in ("value", "ms_per_step", "kernels_ms", "ro
 # HBM traffic of the dominant kernel, per launch: FETCH_SIZE / WRITE_SIZE are in KiB; gfx950
 # FETCH_SIZE counts half of a 16-B-per-lane stream (MI355X_MICROARCH.md "HBM"), so it is doubled.
 dom = bench["roofline"]["kernel"]
-names = {"dense": ("denseStream", "denseGroups", "denseTiles", "denseShared"), "sparse": ("sparseEntries",), "convert": ("convertOperands",)}[dom]
+names = {"dense": ("denseStream", "denseGroups", "denseTiles", "denseShared", "denseSweep"), "sparse": ("sparseEntries",), "convert": ("convertOperands",)}[dom]
 # (a tuned run launches every candidate engine a few times: the steps' kernel is the one with the most launches)
 matching = [(c["FETCH_SIZE"]["launches"], k) for k, c in pmc.items() if any(n in k for n in names) and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
 for k, c in pmc.items():
