@@ -38,8 +38,16 @@ out = {"bench": {k: bench[k] for k in ("value", "ms_per_step", "kernels_ms", "ro
 # FETCH_SIZE counts half of a 16-B-per-lane stream (MI355X_MICROARCH.md "HBM"), so it is doubled.
 dom = bench["roofline"]["kernel"]
 names = {"dense": ("denseStream", "denseGroups", "denseTiles", "denseShared", "denseSweep"), "sparse": ("sparseEntries",), "convert": ("convertOperands",)}[dom]
+# (a tuned run launches every candidate engine a few times - more often than the steps of a short counter pass: the steps'
+# kernel is an instantiation of the engine the bench line names)
+chosen = (bench.get("dense_engine") or {}).get("chosen")
+if dom == "dense" and chosen in ("stream", "tiles", "shared", "sweep"):
+    names = {"stream": ("denseStream", "denseGroups"), "tiles": ("denseTiles",), "shared": ("denseShared",), "sweep": ("denseSweep",)}[chosen]
 # (a tuned run launches every candidate engine a few times: the steps' kernel is the one with the most launches)
-matching = [(c["FETCH_SIZE"]["launches"], k) for k, c in pmc.items() if any(n in k for n in names) and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
+trace_ms = {r["Name"].split("(")[0].replace("void ", ""): float(r["AverageNs"]) / 1e6 for r in csv.DictReader(open(stats))}
+want_ms = bench["kernels_ms"].get(f"{dom}_ms", 0.0)
+# ... and of its instantiations the one whose traced duration is closest to the bench line's kernel time
+matching = [(-abs(trace_ms.get(k, 1e9) - want_ms), k) for k, c in pmc.items() if any(n in k for n in names) and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
 for k, c in pmc.items():
     if matching and k == max(matching)[1]:
         traffic = int((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
