@@ -24,6 +24,7 @@
 
 #include "cluster_kernels.hpp"
 #include "pack_device.hpp"
+#include "promote_device.hpp"
 #include "plan_pack.hpp"
 #include "plan_promote.hpp"
 #include "sddmm_kernels.hpp"
@@ -122,6 +123,7 @@ struct bsmr_plan {
     uint64_t promotedEntries = 0;  // residue entries of the RPHM that the plan computes as extra dense blocks
     float buildMs[5] = {0, 0, 0, 0, 0};  // bsmr_plan_build_times: rules, packing, upload, second format, total
     bool packedOnDevice = false;   // fmt[0] was built by csrc/pack_device.hpp
+    bool promotedOnDevice = false; // ... from blocks the promotion rule built on the device (csrc/promote_device.hpp)
     bool convertPass = false;      // F16/BF16 calls start with the fp32 -> 16-bit pass over A and B
     bool convertBOnly = false;     // no dense part: calls with enough work convert B alone, the residue rounds A while staging
     uint64_t bOnlyWork = 0;        // ... residue entries x K from which that pays
@@ -345,10 +347,146 @@ void dropDense(DenseFormat& f) {
     f = DenseFormat{};
 }
 
+// csrc/plan_promote.hpp's rule on the device (csrc/promote_device.hpp).  BSMR_OK: `applied` says whether blocks were promoted
+// (then out.desc describes the promoted RPHM: offsets and the kept residue on the host, dense_cols / block_values on the
+// device as out.dCols / out.dValues); kPackOnHost: an input the device rule does not do - the host rule decides.
+struct DevicePromotion {
+    DeviceBuffers dev;   // owns dCols / dValues
+    uint32_t *dCols = nullptr, *dValues = nullptr;
+    std::vector<uint32_t> denseCols, blockOffsets, sparseOffsets, sparseValues, sparseRows, sparseCols;
+    bsmr_rphm_desc desc{};   // block_values is NULL: the values live in dValues only
+    uint64_t promotedEntries = 0, promotedBlocks = 0;
+};
+
+int promoteOnDevice(const bsmr_rphm_desc& in, uint32_t minAverage, uint64_t minEntries, uint64_t smallDense, uint32_t minColumnDegree,
+                    uint32_t headMin, DevicePromotion& out, bool& applied) {
+    applied = false;
+    const uint32_t P = in.num_row_panels;
+    const uint64_t numSparse = in.sparse_value_offsets[P];
+    if (minAverage == 0 || numSparse == 0) return BSMR_OK;
+    if ((uint64_t)in.nnz < (uint64_t)minColumnDegree * in.N) return BSMR_OK;
+    if (headMin != 0 || P == 0 || numSparse > 0x7FFFFFF0ull) return kPackOnHost;
+    const uint64_t oldBlocks = in.block_offsets[P];
+    hipStream_t s = nullptr;
+    DeviceBuffers scratch;
+    uint32_t *dSparseOffsets, *dSparseCols, *dSparseRows, *dSparseValues, *dRunOf, *dRunCol, *dRunFirst, *dRunRank, *dColByRank, *dCell;
+    uint32_t *dPanelRuns, *dPanelQualifies, *dPanelMovable, *dFlags;
+    if (!scratch.alloc(&dSparseOffsets, (size_t)P + 1, "hipMalloc") || !scratch.alloc(&dSparseCols, numSparse, "hipMalloc") ||
+        !scratch.alloc(&dSparseRows, numSparse, "hipMalloc") || !scratch.alloc(&dSparseValues, numSparse, "hipMalloc") ||
+        !scratch.alloc(&dRunOf, numSparse, "hipMalloc") || !scratch.alloc(&dRunCol, numSparse, "hipMalloc") ||
+        !scratch.alloc(&dRunFirst, numSparse, "hipMalloc") || !scratch.alloc(&dRunRank, numSparse, "hipMalloc") ||
+        !scratch.alloc(&dColByRank, numSparse, "hipMalloc") || !scratch.alloc(&dCell, numSparse, "hipMalloc") ||
+        !scratch.alloc(&dPanelRuns, P, "hipMalloc") || !scratch.alloc(&dPanelQualifies, P, "hipMalloc") ||
+        !scratch.alloc(&dPanelMovable, P, "hipMalloc") || !scratch.alloc(&dFlags, 1, "hipMalloc"))
+        return kPackOnHost;   // (no room for the scratch arrays: the host rule needs none on the device)
+    BSMR_HIP(hipMemcpyAsync(dSparseOffsets, in.sparse_value_offsets, ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
+    BSMR_HIP(hipMemcpyAsync(dSparseCols, in.sparse_col_indices, numSparse * 4, hipMemcpyHostToDevice, s));
+    BSMR_HIP(hipMemcpyAsync(dSparseRows, in.sparse_relative_rows, numSparse * 4, hipMemcpyHostToDevice, s));
+    BSMR_HIP(hipMemcpyAsync(dSparseValues, in.sparse_values, numSparse * 4, hipMemcpyHostToDevice, s));
+    BSMR_HIP(hipMemsetAsync(dFlags, 0, 4, s));
+    // a panel's residue in column order (ties in the RPHM's order)
+    uint64_t *dKeys, *dKeysAlt;
+    uint32_t *dOrder, *dOrderAlt;
+    if (!scratch.alloc(&dKeys, numSparse, "hipMalloc") || !scratch.alloc(&dKeysAlt, numSparse, "hipMalloc") ||
+        !scratch.alloc(&dOrder, numSparse, "hipMalloc") || !scratch.alloc(&dOrderAlt, numSparse, "hipMalloc"))
+        return kPackOnHost;
+    hipLaunchKernelGGL(bsmr::promoteKeys, dim3((uint32_t)((numSparse + 255) / 256)), dim3(256), 0, s, dSparseOffsets, dSparseCols, P,
+                       (uint32_t)numSparse, dKeys, dOrder);
+    BSMR_HIP(hipGetLastError());
+    int panelBits = 1;
+    while ((1ull << panelBits) < (uint64_t)P) ++panelBits;
+    hipcub::DoubleBuffer<uint64_t> kb(dKeys, dKeysAlt);
+    hipcub::DoubleBuffer<uint32_t> vb(dOrder, dOrderAlt);
+    size_t sortBytes = 0;
+    BSMR_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, kb, vb, (int)numSparse, 0, 32 + panelBits, s));
+    uint8_t* dTemp = nullptr;
+    if (!scratch.alloc(&dTemp, sortBytes + 256, "hipMalloc(sort scratch)")) return kPackOnHost;
+    BSMR_HIP(hipcub::DeviceRadixSort::SortPairs(dTemp, sortBytes, kb, vb, (int)numSparse, 0, 32 + panelBits, s));
+    hipLaunchKernelGGL(bsmr::promotePanels, dim3(P), dim3(256), 0, s, dSparseOffsets, kb.Current(), vb.Current(), dSparseRows, in.N, minAverage,
+                       dRunOf, dRunCol, dRunFirst, dRunRank, dColByRank, dCell, dPanelRuns, dPanelQualifies, dPanelMovable, dFlags);
+    BSMR_HIP(hipGetLastError());
+    std::vector<uint32_t> runs(P), qualifies(P), movable(P);
+    uint32_t flags = 0;
+    BSMR_HIP(hipMemcpyAsync(runs.data(), dPanelRuns, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipMemcpyAsync(qualifies.data(), dPanelQualifies, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipMemcpyAsync(movable.data(), dPanelMovable, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipMemcpyAsync(&flags, dFlags, 4, hipMemcpyDeviceToHost, s));
+    BSMR_HIP(hipStreamSynchronize(s));
+    if (flags) return kPackOnHost;   // malformed (the host path reports it) or not in the device rule's form
+    // which panels: exactly csrc/plan_promote.hpp
+    const uint64_t oldDense = in.nnz >= numSparse ? in.nnz - numSparse : 0;
+    uint64_t qualified = 0;
+    for (uint32_t q = 0; q < P; ++q)
+        if (qualifies[q]) qualified += in.sparse_value_offsets[q + 1] - in.sparse_value_offsets[q];
+    const bool hasDense = oldBlocks != 0 && oldDense >= smallDense;
+    const bool everything = (hasDense || qualified >= minEntries) && (numSparse - qualified) * 4 < in.nnz;
+    std::vector<uint32_t> take(P, 0);
+    uint64_t totalMoved = 0, totalNew = 0;
+    for (uint32_t q = 0; q < P; ++q) {
+        take[q] = everything || qualifies[q] ? (runs[q] + 15u) / 16u : 0u;
+        totalNew += take[q];
+        if (take[q]) totalMoved += movable[q];
+    }
+    if (totalNew == 0 || (!hasDense && totalMoved < minEntries)) return BSMR_OK;
+    if (oldBlocks + totalNew > 0x00FFFFFFull) return BSMR_OK;
+    out.blockOffsets.assign((size_t)P + 1, 0);
+    out.sparseOffsets.assign((size_t)P + 1, 0);
+    for (uint32_t q = 0; q < P; ++q) {
+        out.blockOffsets[q + 1] = out.blockOffsets[q] + (in.block_offsets[q + 1] - in.block_offsets[q]) + take[q];
+        const uint32_t n = in.sparse_value_offsets[q + 1] - in.sparse_value_offsets[q];
+        out.sparseOffsets[q + 1] = out.sparseOffsets[q] + (take[q] ? n - movable[q] : n);
+    }
+    const uint64_t blocks = out.blockOffsets[P], kept = out.sparseOffsets[P];
+    uint32_t *dTake, *dNewOffsets, *dNewSparseOffsets, *dOldOffsets, *dOldCols, *dOldValues, *dKeptValues, *dKeptRows, *dKeptCols;
+    if (!scratch.alloc(&dTake, P, "hipMalloc") || !scratch.alloc(&dNewOffsets, (size_t)P + 1, "hipMalloc") ||
+        !scratch.alloc(&dNewSparseOffsets, (size_t)P + 1, "hipMalloc") || !scratch.alloc(&dOldOffsets, (size_t)P + 1, "hipMalloc") ||
+        !scratch.alloc(&dOldCols, std::max<uint64_t>(oldBlocks * 16, 1), "hipMalloc") ||
+        !scratch.alloc(&dOldValues, std::max<uint64_t>(oldBlocks * 256, 1), "hipMalloc") ||
+        !scratch.alloc(&dKeptValues, std::max<uint64_t>(kept, 1), "hipMalloc") || !scratch.alloc(&dKeptRows, std::max<uint64_t>(kept, 1), "hipMalloc") ||
+        !scratch.alloc(&dKeptCols, std::max<uint64_t>(kept, 1), "hipMalloc") || !out.dev.alloc(&out.dCols, blocks * 16, "hipMalloc") ||
+        !out.dev.alloc(&out.dValues, blocks * 256, "hipMalloc"))
+        return kPackOnHost;
+    BSMR_HIP(hipMemcpyAsync(dTake, take.data(), (size_t)P * 4, hipMemcpyHostToDevice, s));
+    BSMR_HIP(hipMemcpyAsync(dNewOffsets, out.blockOffsets.data(), ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
+    BSMR_HIP(hipMemcpyAsync(dNewSparseOffsets, out.sparseOffsets.data(), ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
+    BSMR_HIP(hipMemcpyAsync(dOldOffsets, in.block_offsets, ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
+    if (oldBlocks) {
+        BSMR_HIP(hipMemcpyAsync(dOldCols, in.dense_cols, oldBlocks * 64, hipMemcpyHostToDevice, s));
+        BSMR_HIP(hipMemcpyAsync(dOldValues, in.block_values, oldBlocks * 1024, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(bsmr::promoteScatter, dim3(P), dim3(256), 0, s, dOldOffsets, dOldCols, dOldValues, dSparseOffsets, dSparseValues,
+                       dSparseRows, dSparseCols, dCell, dColByRank, dPanelRuns, dTake, dNewOffsets, dNewSparseOffsets, in.N, out.dCols,
+                       out.dValues, dKeptValues, dKeptRows, dKeptCols);
+    BSMR_HIP(hipGetLastError());
+    out.sparseValues.resize(kept);
+    out.sparseRows.resize(kept);
+    out.sparseCols.resize(kept);
+    out.denseCols.resize(blocks * 16);   // (64 bytes per block: the host still counts union columns from them)
+    BSMR_HIP(hipMemcpyAsync(out.denseCols.data(), out.dCols, blocks * 64, hipMemcpyDeviceToHost, s));
+    if (kept) {
+        BSMR_HIP(hipMemcpyAsync(out.sparseValues.data(), dKeptValues, kept * 4, hipMemcpyDeviceToHost, s));
+        BSMR_HIP(hipMemcpyAsync(out.sparseRows.data(), dKeptRows, kept * 4, hipMemcpyDeviceToHost, s));
+        BSMR_HIP(hipMemcpyAsync(out.sparseCols.data(), dKeptCols, kept * 4, hipMemcpyDeviceToHost, s));
+    }
+    BSMR_HIP(hipStreamSynchronize(s));
+    out.desc = in;
+    out.desc.dense_cols = out.denseCols.data();
+    out.desc.block_values = nullptr;    // on the device only: out.dValues
+    out.desc.block_offsets = out.blockOffsets.data();
+    out.desc.sparse_value_offsets = out.sparseOffsets.data();
+    out.desc.sparse_values = out.sparseValues.data();
+    out.desc.sparse_relative_rows = out.sparseRows.data();
+    out.desc.sparse_col_indices = out.sparseCols.data();
+    out.promotedEntries = totalMoved;
+    out.promotedBlocks = totalNew;
+    applied = true;
+    return BSMR_OK;
+}
+
 // The default dense layout (one panel per group, blocks in column order, window offsets) from the RPHM arrays, on the
 // current device.  BSMR_OK: `f` is complete; kPackOnHost: nothing is kept, the host packer has to do this plan.
 int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, const std::vector<uint32_t>& panelRows, DenseFormat& f,
-                      uint64_t& indexBytes, DevicePackResult& r) {
+                      uint64_t& indexBytes, DevicePackResult& r, uint32_t* residentCols = nullptr, uint32_t* residentValues = nullptr) {
     const uint32_t P = d->num_row_panels;
     const uint64_t oldBlocks = d->block_offsets[P], slots = oldBlocks * 16;
     if (oldBlocks == 0 || slots > 0x7FFFFFFFull || P == 0) return kPackOnHost;
@@ -357,16 +495,20 @@ int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, con
     uint32_t *dCols, *dOffsets, *dValues, *dSlots, *dSlotsAlt, *dPanelCols, *dPanelBlocks, *dFirstBlock, *dFlags, *dMaxItem;
     uint64_t *dKeys, *dKeysAlt;
     unsigned long long* dCounters;
-    if (!dev.alloc(&dCols, slots, "hipMalloc") || !dev.alloc(&dOffsets, (size_t)P + 1, "hipMalloc") ||
-        !dev.alloc(&dValues, oldBlocks * 256, "hipMalloc") || !dev.alloc(&dKeys, slots, "hipMalloc") ||
+    // (dense_cols / block_values already on the device: the promotion rule ran there, csrc/promote_device.hpp)
+    const bool resident = residentCols && residentValues;
+    dCols = residentCols;
+    dValues = residentValues;
+    if ((!resident && (!dev.alloc(&dCols, slots, "hipMalloc") || !dev.alloc(&dValues, oldBlocks * 256, "hipMalloc"))) ||
+        !dev.alloc(&dOffsets, (size_t)P + 1, "hipMalloc") || !dev.alloc(&dKeys, slots, "hipMalloc") ||
         !dev.alloc(&dKeysAlt, slots, "hipMalloc") || !dev.alloc(&dSlots, slots, "hipMalloc") ||
         !dev.alloc(&dSlotsAlt, slots, "hipMalloc") || !dev.alloc(&dPanelCols, (size_t)P + 1, "hipMalloc") ||
         !dev.alloc(&dPanelBlocks, (size_t)P + 1, "hipMalloc") || !dev.alloc(&dFirstBlock, (size_t)P + 1, "hipMalloc") ||
         !dev.alloc(&dFlags, 1, "hipMalloc") || !dev.alloc(&dMaxItem, 1, "hipMalloc") || !dev.alloc(&dCounters, 2, "hipMalloc"))
         return BSMR_ERR_OOM;
-    BSMR_HIP(hipMemcpyAsync(dCols, d->dense_cols, slots * 4, hipMemcpyHostToDevice, s));
+    if (!resident) BSMR_HIP(hipMemcpyAsync(dCols, d->dense_cols, slots * 4, hipMemcpyHostToDevice, s));
     BSMR_HIP(hipMemcpyAsync(dOffsets, d->block_offsets, ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
-    BSMR_HIP(hipMemcpyAsync(dValues, d->block_values, oldBlocks * 1024, hipMemcpyHostToDevice, s));
+    if (!resident) BSMR_HIP(hipMemcpyAsync(dValues, d->block_values, oldBlocks * 1024, hipMemcpyHostToDevice, s));
     BSMR_HIP(hipMemsetAsync(dFlags, 0, 4, s));
     BSMR_HIP(hipMemsetAsync(dMaxItem, 0, 4, s));
     BSMR_HIP(hipMemsetAsync(dCounters, 0, 16, s));
@@ -1514,6 +1656,7 @@ int bsmr_plan_options_default(bsmr_plan_options* opt) {
     o.sweep_waves = 0;
     o.sweep_per_cu = 0;
     o.k_hint = 0;
+    o.promote_on_device = -1;
     *opt = o;
     return BSMR_OK;
 }
@@ -1541,7 +1684,7 @@ int bsmr_plan_options_from_env(bsmr_plan_options* opt) {
         {"BSMR_B_ONLY_WORK_M", &o.b_only_work_m}, {"BSMR_OVERLAP_STREAMS", &o.overlap_streams},
         {"BSMR_MASK_TILES", &o.mask_tiles}, {"BSMR_PACK_ON_DEVICE", &o.pack_on_device},
         {"BSMR_SWEEP_PANELS", &o.sweep_panels}, {"BSMR_SWEEP_BLOCKS", &o.sweep_strip_blocks}, {"BSMR_SWEEP_FP32", &o.sweep_fp32},
-        {"BSMR_SWEEP_WAVES", &o.sweep_waves}, {"BSMR_SWEEP_PER_CU", &o.sweep_per_cu}, {"BSMR_K_HINT", &o.k_hint},
+        {"BSMR_SWEEP_WAVES", &o.sweep_waves}, {"BSMR_SWEEP_PER_CU", &o.sweep_per_cu}, {"BSMR_K_HINT", &o.k_hint}, {"BSMR_PROMOTE_ON_DEVICE", &o.promote_on_device},
     };
     for (const auto& k : knobs) *k.field = envInt(k.name, *k.field);
     return BSMR_OK;
@@ -1604,7 +1747,34 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         bsmr::PromotedRphm promoted;
         uint64_t promotedEntries = 0;
         const uint64_t foldBelow = (uint64_t)std::max(0, o.fold_dense_below);
-        if (offsetsOk && numSparse && (d->sparse_values && d->sparse_relative_rows && d->sparse_col_indices) &&
+        // The same rule on the device (csrc/promote_device.hpp) when everything that follows can take its result there: the
+        // default dense layout packed by kernels, no engine that needs the dense entries on the host, no folding afterwards.
+        // What it leaves: the promoted dense arrays in device memory (never uploaded: 1 KiB per block), offsets and the kept
+        // residue on the host.  Anything it does not do falls through to the host rule below.
+        DevicePromotion onDevice;
+        bool promotedOnDevice = false;
+        const bool hostDenseNeeded = o.dense_engine == BSMR_ENGINE_TILES || o.dense_engine == BSMR_ENGINE_SHARED ||
+                                     o.dense_engine == BSMR_ENGINE_TUNED || o.dense_engine == BSMR_ENGINE_SWEEP;
+        const bool deviceLayout = o.dense_group <= 1 && o.column_order != 0 && o.output_mode != 0 && !o.force_tile32 && o.pack_on_device != 0 &&
+                                  !envInt("BSMR_ITEM_ORDER", 0) && !envInt("BSMR_ITEM_SPAN", 0);
+        if (offsetsOk && numSparse && !hostDenseNeeded && deviceLayout &&
+            (o.promote_on_device > 0 || (o.promote_on_device < 0 && numSparse >= (1u << 20)))) {
+            bool applied = false;
+            st = promoteOnDevice(*d, (uint32_t)std::max(0, o.promote_average), (uint64_t)std::max(0, o.promote_min_entries_k) * 1000ull, foldBelow,
+                                 (uint32_t)std::max(0, o.promote_column_degree), (uint32_t)std::max(0, o.promote_head), onDevice, applied);
+            if (st != BSMR_OK && st != kPackOnHost) return st;
+            if (st == BSMR_OK && applied) {
+                const uint64_t blocksNow = onDevice.desc.block_offsets[P];
+                // (a dense part that would still be folded, or too small for the device packer's own rule: the host path)
+                if (d->nnz - onDevice.desc.sparse_value_offsets[P] >= foldBelow && (o.pack_on_device > 0 || blocksNow >= 4096)) {
+                    d = &onDevice.desc;
+                    promotedEntries = onDevice.promotedEntries;
+                    promotedOnDevice = true;
+                }
+            }
+            st = BSMR_OK;
+        }
+        if (!promotedOnDevice && offsetsOk && numSparse && (d->sparse_values && d->sparse_relative_rows && d->sparse_col_indices) &&
             bsmr::promoteSparseBlocks(*d, (uint32_t)std::max(0, o.promote_average),
                                       (uint64_t)std::max(0, o.promote_min_entries_k) * 1000ull, foldBelow,
                                       (uint32_t)std::max(0, o.promote_column_degree),
@@ -1705,7 +1875,8 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
             (o.pack_on_device > 0 || (o.pack_on_device < 0 && d->block_offsets[P] >= 4096))) {
             DevicePackResult r;
             if ((st = bsmr::packRows(d, pk)) != BSMR_OK) return st;
-            st = packDenseOnDevice(d, opt, pk.panelRows, deviceFormat, deviceFormatBytes, r);
+            st = packDenseOnDevice(d, opt, pk.panelRows, deviceFormat, deviceFormatBytes, r, promotedOnDevice ? onDevice.dCols : nullptr,
+                                   promotedOnDevice ? onDevice.dValues : nullptr);
             if (st == BSMR_OK) {
                 pk.H = 1;
                 pk.numGroups = P;
@@ -1723,6 +1894,11 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
                 return st;
             }
         }
+        if (!packedOnDevice && promotedOnDevice) {   // the packer leaves this layout to the host: so does the rule, from the start
+            bsmr_plan_options again = o;
+            again.promote_on_device = 0;
+            return bsmr_plan_create_ex(out, device, given, &again);
+        }
         if (!packedOnDevice) {
             pk = bsmr::PackedPlan();
             st = bsmr::packPlan(d, opt, pk);
@@ -1737,6 +1913,7 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         }
         p->device = device;
         p->packedOnDevice = packedOnDevice;
+        p->promotedOnDevice = promotedOnDevice;
         p->M = d->M;
         p->N = d->N;
         p->nnz = d->nnz;
@@ -1824,6 +2001,13 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         // cases in which it has ever won; for a tunable plan bsmr_plan_tune then measures which of the two serves a (K, mode))
         const uint64_t grouped4 = st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8
                                       ? bsmr::countUnionColumns(d, 4) : 0;
+        if (grouped4 && pk.unionColumns * 2 >= 5 * grouped4 && promotedOnDevice) {   // (the host packer builds that one: it needs the values)
+            freePlanDevice(p);
+            delete p;
+            bsmr_plan_options again = o;
+            again.promote_on_device = 0;
+            return bsmr_plan_create_ex(out, device, given, &again);
+        }
         if (grouped4 && pk.unionColumns * 2 >= 5 * grouped4) {
             bsmr::PackedPlan pk4;
             opt.group = 4;
@@ -1933,6 +2117,13 @@ int bsmr_plan_build_times(const bsmr_plan* p, bsmr_plan_build_ms* out) {
     out->upload_ms = p->buildMs[2];
     out->second_format_ms = p->buildMs[3];
     out->total_ms = p->buildMs[4];
+    return BSMR_OK;
+}
+
+int bsmr_plan_promoted_on_device(const bsmr_plan* plan, int* yes) {
+    plan = served(plan);
+    if (!plan || !yes) return BSMR_ERR_INVALID_ARG;
+    *yes = plan->promotedOnDevice ? 1 : 0;
     return BSMR_OK;
 }
 

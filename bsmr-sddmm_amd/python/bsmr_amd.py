@@ -81,7 +81,7 @@ class PlanOptions(C.Structure):
         "column_order", "dense_stream", "dense_batch", "tile_group", "tile_blocks_per_item", "tile_depth",
         "sparse_entries_per_item", "sparse_lowp", "sparse_lpe", "free_residue", "convert_in_kernel", "convert_sliced",
         "b_only", "b_only_work_m", "overlap_streams", "mask_tiles", "pack_on_device", "sweep_panels", "sweep_strip_blocks",
-        "sweep_fp32", "sweep_waves", "sweep_per_cu", "k_hint")]
+        "sweep_fp32", "sweep_waves", "sweep_per_cu", "k_hint", "promote_on_device")]
 
 
 ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED, ENGINE_TUNED, ENGINE_SWEEP = 0, 1, 2, 3, 4
@@ -134,6 +134,7 @@ HIP_SYMBOLS = {
     "bsmr_plan_options_default": (C.c_int, [C.POINTER(PlanOptions)]),
     "bsmr_plan_options_from_env": (C.c_int, [C.POINTER(PlanOptions)]),
     "bsmr_plan_destroy": (C.c_int, [C.c_void_p]),
+    "bsmr_plan_promoted_on_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "bsmr_plan_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
     "bsmr_plan_build_times": (C.c_int, [C.c_void_p, C.POINTER(PlanBuildMs)]),
     "bsmr_plan_format_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

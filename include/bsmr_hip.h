@@ -107,6 +107,9 @@ typedef struct bsmr_plan_stats {
     uint64_t promoted_sparse_entries; /* residue entries (RPHM) that the plan computes as extra dense blocks */
 } bsmr_plan_stats;
 
+/* 1 when the promotion rule of this plan ran as kernels (bsmr_plan_options.promote_on_device), 0 when on the host. */
+int bsmr_plan_promoted_on_device(const bsmr_plan *plan, int *yes);
+
 /* Kernel timings of the last bsmr_sddmm_timed call, milliseconds per iteration. */
 typedef struct bsmr_timing {
     float total_ms;    /* convert + dense + sparse, wall on the stream          */
@@ -201,6 +204,10 @@ typedef struct bsmr_plan_options {
                                        will mostly be called with - the plan keeps a copy of the RPHM arrays, and
                                        bsmr_plan_tune builds it under the other settings of those rules too
                                        (BSMR_VARIANT_*), times whole calls and lets the fastest serve the plan  [K_HINT] */
+    int32_t  promote_on_device;     /* the promotion rule as kernels (csrc/promote_device.hpp), its blocks handed to the device
+                                       packer without crossing PCIe: -1 = from 2^20 residue entries when the plan's layout
+                                       and engine allow, 0 = never, 1 = whenever they allow.  Same plan, byte for byte
+                                                                                                         [PROMOTE_ON_DEVICE] */
 } bsmr_plan_options;
 int bsmr_plan_options_default(bsmr_plan_options *opt);
 /* defaults, then every BSMR_<NAME> variable that is set */
