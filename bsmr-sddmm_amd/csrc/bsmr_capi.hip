@@ -350,6 +350,11 @@ void dropDense(DenseFormat& f) {
 // csrc/plan_promote.hpp's rule on the device (csrc/promote_device.hpp).  BSMR_OK: `applied` says whether blocks were promoted
 // (then out.desc describes the promoted RPHM: offsets and the kept residue on the host, dense_cols / block_values on the
 // device as out.dCols / out.dValues); kPackOnHost: an input the device rule does not do - the host rule decides.
+// the big RPHM arrays where bsmr_col_reorder left them (bsmr_plan_create_from_colreorder); not owned
+struct ResidentRphm {
+    uint32_t *denseCols, *blockValues, *sparseValues, *sparseRows, *sparseCols;
+};
+
 struct DevicePromotion {
     DeviceBuffers dev;   // owns dCols / dValues
     uint32_t *dCols = nullptr, *dValues = nullptr;
@@ -359,7 +364,7 @@ struct DevicePromotion {
 };
 
 int promoteOnDevice(const bsmr_rphm_desc& in, uint32_t minAverage, uint64_t minEntries, uint64_t smallDense, uint32_t minColumnDegree,
-                    uint32_t headMin, DevicePromotion& out, bool& applied) {
+                    uint32_t headMin, DevicePromotion& out, bool& applied, const ResidentRphm* res = nullptr) {
     applied = false;
     const uint32_t P = in.num_row_panels;
     const uint64_t numSparse = in.sparse_value_offsets[P];
@@ -371,8 +376,12 @@ int promoteOnDevice(const bsmr_rphm_desc& in, uint32_t minAverage, uint64_t minE
     DeviceBuffers scratch;
     uint32_t *dSparseOffsets, *dSparseCols, *dSparseRows, *dSparseValues, *dRunOf, *dRunCol, *dRunFirst, *dRunRank, *dColByRank, *dCell;
     uint32_t *dPanelRuns, *dPanelQualifies, *dPanelMovable, *dFlags;
-    if (!scratch.alloc(&dSparseOffsets, (size_t)P + 1, "hipMalloc") || !scratch.alloc(&dSparseCols, numSparse, "hipMalloc") ||
-        !scratch.alloc(&dSparseRows, numSparse, "hipMalloc") || !scratch.alloc(&dSparseValues, numSparse, "hipMalloc") ||
+    dSparseCols = res ? res->sparseCols : nullptr;
+    dSparseRows = res ? res->sparseRows : nullptr;
+    dSparseValues = res ? res->sparseValues : nullptr;
+    if (!scratch.alloc(&dSparseOffsets, (size_t)P + 1, "hipMalloc") ||
+        (!res && (!scratch.alloc(&dSparseCols, numSparse, "hipMalloc") || !scratch.alloc(&dSparseRows, numSparse, "hipMalloc") ||
+                  !scratch.alloc(&dSparseValues, numSparse, "hipMalloc"))) ||
         !scratch.alloc(&dRunOf, numSparse, "hipMalloc") || !scratch.alloc(&dRunCol, numSparse, "hipMalloc") ||
         !scratch.alloc(&dRunFirst, numSparse, "hipMalloc") || !scratch.alloc(&dRunRank, numSparse, "hipMalloc") ||
         !scratch.alloc(&dColByRank, numSparse, "hipMalloc") || !scratch.alloc(&dCell, numSparse, "hipMalloc") ||
@@ -380,9 +389,11 @@ int promoteOnDevice(const bsmr_rphm_desc& in, uint32_t minAverage, uint64_t minE
         !scratch.alloc(&dPanelMovable, P, "hipMalloc") || !scratch.alloc(&dFlags, 1, "hipMalloc"))
         return kPackOnHost;   // (no room for the scratch arrays: the host rule needs none on the device)
     BSMR_HIP(hipMemcpyAsync(dSparseOffsets, in.sparse_value_offsets, ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
-    BSMR_HIP(hipMemcpyAsync(dSparseCols, in.sparse_col_indices, numSparse * 4, hipMemcpyHostToDevice, s));
-    BSMR_HIP(hipMemcpyAsync(dSparseRows, in.sparse_relative_rows, numSparse * 4, hipMemcpyHostToDevice, s));
-    BSMR_HIP(hipMemcpyAsync(dSparseValues, in.sparse_values, numSparse * 4, hipMemcpyHostToDevice, s));
+    if (!res) {
+        BSMR_HIP(hipMemcpyAsync(dSparseCols, in.sparse_col_indices, numSparse * 4, hipMemcpyHostToDevice, s));
+        BSMR_HIP(hipMemcpyAsync(dSparseRows, in.sparse_relative_rows, numSparse * 4, hipMemcpyHostToDevice, s));
+        BSMR_HIP(hipMemcpyAsync(dSparseValues, in.sparse_values, numSparse * 4, hipMemcpyHostToDevice, s));
+    }
     BSMR_HIP(hipMemsetAsync(dFlags, 0, 4, s));
     // a panel's residue in column order (ties in the RPHM's order)
     uint64_t *dKeys, *dKeysAlt;
@@ -440,8 +451,8 @@ int promoteOnDevice(const bsmr_rphm_desc& in, uint32_t minAverage, uint64_t minE
     uint32_t *dTake, *dNewOffsets, *dNewSparseOffsets, *dOldOffsets, *dOldCols, *dOldValues, *dKeptValues, *dKeptRows, *dKeptCols;
     if (!scratch.alloc(&dTake, P, "hipMalloc") || !scratch.alloc(&dNewOffsets, (size_t)P + 1, "hipMalloc") ||
         !scratch.alloc(&dNewSparseOffsets, (size_t)P + 1, "hipMalloc") || !scratch.alloc(&dOldOffsets, (size_t)P + 1, "hipMalloc") ||
-        !scratch.alloc(&dOldCols, std::max<uint64_t>(oldBlocks * 16, 1), "hipMalloc") ||
-        !scratch.alloc(&dOldValues, std::max<uint64_t>(oldBlocks * 256, 1), "hipMalloc") ||
+        (!res && (!scratch.alloc(&dOldCols, std::max<uint64_t>(oldBlocks * 16, 1), "hipMalloc") ||
+                  !scratch.alloc(&dOldValues, std::max<uint64_t>(oldBlocks * 256, 1), "hipMalloc"))) ||
         !scratch.alloc(&dKeptValues, std::max<uint64_t>(kept, 1), "hipMalloc") || !scratch.alloc(&dKeptRows, std::max<uint64_t>(kept, 1), "hipMalloc") ||
         !scratch.alloc(&dKeptCols, std::max<uint64_t>(kept, 1), "hipMalloc") || !out.dev.alloc(&out.dCols, blocks * 16, "hipMalloc") ||
         !out.dev.alloc(&out.dValues, blocks * 256, "hipMalloc"))
@@ -450,7 +461,10 @@ int promoteOnDevice(const bsmr_rphm_desc& in, uint32_t minAverage, uint64_t minE
     BSMR_HIP(hipMemcpyAsync(dNewOffsets, out.blockOffsets.data(), ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
     BSMR_HIP(hipMemcpyAsync(dNewSparseOffsets, out.sparseOffsets.data(), ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
     BSMR_HIP(hipMemcpyAsync(dOldOffsets, in.block_offsets, ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
-    if (oldBlocks) {
+    if (res) {
+        dOldCols = res->denseCols;
+        dOldValues = res->blockValues;
+    } else if (oldBlocks) {
         BSMR_HIP(hipMemcpyAsync(dOldCols, in.dense_cols, oldBlocks * 64, hipMemcpyHostToDevice, s));
         BSMR_HIP(hipMemcpyAsync(dOldValues, in.block_values, oldBlocks * 1024, hipMemcpyHostToDevice, s));
     }
@@ -1696,7 +1710,10 @@ int bsmr_plan_create(bsmr_plan** out, int device, const bsmr_rphm_desc* d) {
     return bsmr_plan_create_ex(out, device, d, &o);
 }
 
-int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_plan_options* options) {
+namespace {
+// bsmr_plan_create_ex; with `res` the big arrays of the RPHM are the device arrays of a bsmr_col_reorder result (their host
+// pointers in `d` are NULL) and kPackOnHost means: this plan needs them on the host - fetch them and come back without `res`
+int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_plan_options* options, const ResidentRphm* res) {
     if (!out || !d) return BSMR_ERR_INVALID_ARG;
     *out = nullptr;
     const bsmr_rphm_desc* const given = d;
@@ -1717,9 +1734,10 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         return BSMR_ERR_BAD_PLAN;
     const uint64_t numBlocks = d->block_offsets[P];
     const uint64_t numSparse = d->sparse_value_offsets[P];
-    if (numBlocks && (!d->dense_cols || !d->block_values)) return BSMR_ERR_INVALID_ARG;
-    if (numSparse && (!d->sparse_values || !d->sparse_relative_rows || !d->sparse_col_indices))
+    if (!res && numBlocks && (!d->dense_cols || !d->block_values)) return BSMR_ERR_INVALID_ARG;
+    if (!res && numSparse && (!d->sparse_values || !d->sparse_relative_rows || !d->sparse_col_indices))
         return BSMR_ERR_INVALID_ARG;
+    if (res && o.k_hint > 0) return kPackOnHost;   // (the plan keeps host copies of the arrays)
 
     int st = useDevice(device);
     if (st != BSMR_OK) return st;
@@ -1757,12 +1775,20 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
                                      o.dense_engine == BSMR_ENGINE_TUNED || o.dense_engine == BSMR_ENGINE_SWEEP;
         const bool deviceLayout = o.dense_group <= 1 && o.column_order != 0 && o.output_mode != 0 && !o.force_tile32 && o.pack_on_device != 0 &&
                                   !envInt("BSMR_ITEM_ORDER", 0) && !envInt("BSMR_ITEM_SPAN", 0);
-        if (offsetsOk && numSparse && !hostDenseNeeded && deviceLayout &&
-            (o.promote_on_device > 0 || (o.promote_on_device < 0 && numSparse >= (1u << 20)))) {
+        if (res && (hostDenseNeeded || !deviceLayout || o.promote_on_device == 0)) return kPackOnHost;
+        // (device-resident arrays: the dense part as it is, its column lists and the residue fetched for the host-side steps)
+        struct {
+            std::vector<uint32_t> denseCols, sparseValues, sparseRows, sparseCols;
+            bsmr_rphm_desc desc{};
+        } fetched;
+        bool denseResident = false;
+        if (offsetsOk && (numSparse || res) && !hostDenseNeeded && deviceLayout &&
+            (res || o.promote_on_device > 0 || (o.promote_on_device < 0 && numSparse >= (1u << 20)))) {
             bool applied = false;
             st = promoteOnDevice(*d, (uint32_t)std::max(0, o.promote_average), (uint64_t)std::max(0, o.promote_min_entries_k) * 1000ull, foldBelow,
-                                 (uint32_t)std::max(0, o.promote_column_degree), (uint32_t)std::max(0, o.promote_head), onDevice, applied);
+                                 (uint32_t)std::max(0, o.promote_column_degree), (uint32_t)std::max(0, o.promote_head), onDevice, applied, res);
             if (st != BSMR_OK && st != kPackOnHost) return st;
+            if (st == kPackOnHost && res) return kPackOnHost;
             if (st == BSMR_OK && applied) {
                 const uint64_t blocksNow = onDevice.desc.block_offsets[P];
                 // (a dense part that would still be folded, or too small for the device packer's own rule: the host path)
@@ -1770,11 +1796,33 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
                     d = &onDevice.desc;
                     promotedEntries = onDevice.promotedEntries;
                     promotedOnDevice = true;
+                } else if (res) {
+                    return kPackOnHost;
                 }
+            } else if (st == BSMR_OK && res) {   // nothing promoted: the RPHM's own split
+                const uint64_t denseNow = d->nnz >= numSparse ? d->nnz - numSparse : 0;
+                if (numBlocks && denseNow < foldBelow) return kPackOnHost;   // (folding reads the blocks on the host)
+                fetched.denseCols.resize(numBlocks * 16);
+                fetched.sparseValues.resize(numSparse);
+                fetched.sparseRows.resize(numSparse);
+                fetched.sparseCols.resize(numSparse);
+                if (numBlocks) BSMR_HIP(hipMemcpy(fetched.denseCols.data(), res->denseCols, numBlocks * 64, hipMemcpyDeviceToHost));
+                if (numSparse) {
+                    BSMR_HIP(hipMemcpy(fetched.sparseValues.data(), res->sparseValues, numSparse * 4, hipMemcpyDeviceToHost));
+                    BSMR_HIP(hipMemcpy(fetched.sparseRows.data(), res->sparseRows, numSparse * 4, hipMemcpyDeviceToHost));
+                    BSMR_HIP(hipMemcpy(fetched.sparseCols.data(), res->sparseCols, numSparse * 4, hipMemcpyDeviceToHost));
+                }
+                fetched.desc = *d;
+                fetched.desc.dense_cols = fetched.denseCols.data();
+                fetched.desc.sparse_values = fetched.sparseValues.data();
+                fetched.desc.sparse_relative_rows = fetched.sparseRows.data();
+                fetched.desc.sparse_col_indices = fetched.sparseCols.data();
+                d = &fetched.desc;
+                denseResident = true;
             }
             st = BSMR_OK;
         }
-        if (!promotedOnDevice && offsetsOk && numSparse && (d->sparse_values && d->sparse_relative_rows && d->sparse_col_indices) &&
+        if (!promotedOnDevice && !res && offsetsOk && numSparse && (d->sparse_values && d->sparse_relative_rows && d->sparse_col_indices) &&
             bsmr::promoteSparseBlocks(*d, (uint32_t)std::max(0, o.promote_average),
                                       (uint64_t)std::max(0, o.promote_min_entries_k) * 1000ull, foldBelow,
                                       (uint32_t)std::max(0, o.promote_column_degree),
@@ -1875,8 +1923,9 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
             (o.pack_on_device > 0 || (o.pack_on_device < 0 && d->block_offsets[P] >= 4096))) {
             DevicePackResult r;
             if ((st = bsmr::packRows(d, pk)) != BSMR_OK) return st;
-            st = packDenseOnDevice(d, opt, pk.panelRows, deviceFormat, deviceFormatBytes, r, promotedOnDevice ? onDevice.dCols : nullptr,
-                                   promotedOnDevice ? onDevice.dValues : nullptr);
+            st = packDenseOnDevice(d, opt, pk.panelRows, deviceFormat, deviceFormatBytes, r,
+                                   promotedOnDevice ? onDevice.dCols : (denseResident ? res->denseCols : nullptr),
+                                   promotedOnDevice ? onDevice.dValues : (denseResident ? res->blockValues : nullptr));
             if (st == BSMR_OK) {
                 pk.H = 1;
                 pk.numGroups = P;
@@ -1894,7 +1943,9 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
                 return st;
             }
         }
+        if (!packedOnDevice && denseResident && d->block_offsets[P]) return kPackOnHost;
         if (!packedOnDevice && promotedOnDevice) {   // the packer leaves this layout to the host: so does the rule, from the start
+            if (res) return kPackOnHost;
             bsmr_plan_options again = o;
             again.promote_on_device = 0;
             return bsmr_plan_create_ex(out, device, given, &again);
@@ -2001,9 +2052,10 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
         // cases in which it has ever won; for a tunable plan bsmr_plan_tune then measures which of the two serves a (K, mode))
         const uint64_t grouped4 = st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8
                                       ? bsmr::countUnionColumns(d, 4) : 0;
-        if (grouped4 && pk.unionColumns * 2 >= 5 * grouped4 && promotedOnDevice) {   // (the host packer builds that one: it needs the values)
+        if (grouped4 && pk.unionColumns * 2 >= 5 * grouped4 && (promotedOnDevice || denseResident)) {   // (the host packer builds that one: it needs the values)
             freePlanDevice(p);
             delete p;
+            if (res) return kPackOnHost;
             bsmr_plan_options again = o;
             again.promote_on_device = 0;
             return bsmr_plan_create_ex(out, device, given, &again);
@@ -2057,6 +2109,11 @@ int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, co
     } catch (...) {
         return BSMR_ERR_INVALID_ARG;
     }
+}
+}  // namespace
+
+int bsmr_plan_create_ex(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_plan_options* options) {
+    return createPlan(out, device, d, options, nullptr);
 }
 
 int bsmr_plan_destroy(bsmr_plan* plan) {

@@ -390,4 +390,54 @@ int bsmr_col_reorder_fetch(const bsmr_colreorder* h, uint32_t* dense_cols, uint3
     return st;
 }
 
+int bsmr_col_reorder_device(const bsmr_colreorder* h, int* device) {
+    if (!h || !device) return BSMR_ERR_INVALID_ARG;
+    *device = h->device;
+    return BSMR_OK;
+}
+
+int bsmr_plan_create_from_colreorder(bsmr_plan** out, const bsmr_colreorder* h, uint32_t M, uint32_t N, uint32_t nnz,
+                                     const uint32_t* reordered_rows, uint32_t num_nonzero_rows, const bsmr_plan_options* options) {
+    if (!out || !h) return BSMR_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (h->numBlocks * 16 != h->numDenseCols) return BSMR_ERR_BAD_PLAN;
+    bsmr_plan_options o;
+    if (options) {
+        if (options->struct_size < 2 * sizeof(uint32_t) || options->struct_size > sizeof(bsmr_plan_options)) return BSMR_ERR_INVALID_ARG;
+        bsmr_plan_options_default(&o);
+        memcpy(&o, options, options->struct_size);
+        o.struct_size = (uint32_t)sizeof(bsmr_plan_options);
+    } else {
+        bsmr_plan_options_from_env(&o);
+    }
+    bsmr_rphm_desc d{};
+    d.M = M;
+    d.N = N;
+    d.nnz = nnz;
+    d.num_row_panels = h->numPanels;
+    d.num_nonzero_rows = num_nonzero_rows;
+    d.reordered_rows = reordered_rows;
+    d.block_offsets = h->blockOffsets.data();
+    d.sparse_value_offsets = h->sparseValueOffsets.data();
+    const ResidentRphm res{h->denseCols, h->blockValues, h->sparseValues, h->sparseRows, h->sparseColIdx};
+    int st = createPlan(out, h->device, &d, &o, &res);
+    if (st != kPackOnHost) return st;
+    // this plan needs the arrays on the host (an engine that keeps the dense entries there, a layout of the host packer, ...)
+    try {
+        std::vector<uint32_t> denseCols(h->numDenseCols), blockValues(h->numBlocks * 256), sparseValues(h->numSparseEntries),
+            sparseRows(h->numSparseEntries), sparseCols(h->numSparseEntries);
+        st = bsmr_col_reorder_fetch(h, denseCols.data(), nullptr, nullptr, nullptr, nullptr, nullptr, blockValues.data(), sparseValues.data(),
+                                    sparseRows.data(), sparseCols.data());
+        if (st != BSMR_OK) return st;
+        d.dense_cols = denseCols.data();
+        d.block_values = blockValues.data();
+        d.sparse_values = sparseValues.data();
+        d.sparse_relative_rows = sparseRows.data();
+        d.sparse_col_indices = sparseCols.data();
+        return bsmr_plan_create_ex(out, h->device, &d, &o);
+    } catch (const std::bad_alloc&) {
+        return BSMR_ERR_OOM;
+    }
+}
+
 }  // extern "C"

@@ -12,7 +12,10 @@
 
 #include <string>
 #include <utility>
+#include <memory>
 #include <vector>
+
+struct bsmr_colreorder;   // include/bsmr_hip.h: a column-reordering result on the device
 
 #include "Logger.hpp"
 #include "Matrix.hpp"
@@ -59,9 +62,13 @@ public:
 
     // Index arrays of the RPHM when the column reordering ran on the device (bsmr_col_reorder computes them in the
     // same pass; RPHM::RPHM then takes them instead of rebuilding them on the host).  Empty otherwise.
+    // (round 3: the four big arrays - block values and the residue's three - stay on the device behind `handle`; RPHM
+    // builds its plan from them there, bsmr_plan_create_from_colreorder, and fetches them when somebody asks)
     struct DeviceRphmArrays {
         bool valid = false;
-        std::vector<UIN> blockOffsets, blockValues, sparseValues, sparseRelativeRows, sparseColIndices;
+        std::shared_ptr<bsmr_colreorder> handle;
+        std::vector<UIN> blockOffsets;
+        uint64_t numBlocks = 0, numSparseEntries = 0;
         float deviceMs = 0.0f;
     };
     const DeviceRphmArrays& deviceRphm() const { return deviceRphm_; }
@@ -100,12 +107,12 @@ public:
     UIN numSparseThreadBlocks() const { return numSparseThreadBlocks_; }
     const std::vector<UIN>& reorderedRows() const { return reorderedRows_; }
     const std::vector<UIN>& denseCols() const { return denseCols_; }
-    const std::vector<UIN>& blockValues() const { return blockValues_; }
+    const std::vector<UIN>& blockValues() const { fetchBigArrays(); return blockValues_; }
     const std::vector<UIN>& blockOffsets() const { return blockOffsets_; }
     const std::vector<UIN>& sparseValueOffsets() const { return sparseValueOffsets_; }
-    const std::vector<UIN>& sparseValues() const { return sparseValues_; }
-    const std::vector<UIN>& sparseRelativeRows() const { return sparseRelativeRows_; }
-    const std::vector<UIN>& sparseColIndices() const { return sparseColIndices_; }
+    const std::vector<UIN>& sparseValues() const { fetchBigArrays(); return sparseValues_; }
+    const std::vector<UIN>& sparseRelativeRows() const { fetchBigArrays(); return sparseRelativeRows_; }
+    const std::vector<UIN>& sparseColIndices() const { fetchBigArrays(); return sparseColIndices_; }
     const std::vector<UIN>& denseRowPanelIds() const { return denseRowPanelIds_; }
     const std::vector<UIN>& denseColBlockIters() const { return denseColBlockIters_; }
     const std::vector<UIN>& sparseRowPanelIds() const { return sparseRowPanelIds_; }
@@ -132,6 +139,9 @@ public:
 
 private:
     void release();
+    // the column reordering ran on the device: block values and the residue arrays are copied to the host on first use
+    void fetchBigArrays() const;
+    mutable std::shared_ptr<bsmr_colreorder> onDevice_;
 
     UIN numRowPanels_ = 0;
     UIN maxNumDenseColBlocksInRowPanel_ = 0;
@@ -143,11 +153,11 @@ private:
     std::vector<UIN> reorderedRows_;
     std::vector<UIN> denseCols_;
     std::vector<UIN> blockOffsets_;
-    std::vector<UIN> blockValues_;
+    mutable std::vector<UIN> blockValues_;
     std::vector<UIN> sparseValueOffsets_;
-    std::vector<UIN> sparseValues_;
-    std::vector<UIN> sparseRelativeRows_;
-    std::vector<UIN> sparseColIndices_;
+    mutable std::vector<UIN> sparseValues_;
+    mutable std::vector<UIN> sparseRelativeRows_;
+    mutable std::vector<UIN> sparseColIndices_;
     std::vector<UIN> denseRowPanelIds_;
     std::vector<UIN> denseColBlockIters_;
     std::vector<UIN> sparseRowPanelIds_;

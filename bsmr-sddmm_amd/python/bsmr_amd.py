@@ -135,6 +135,9 @@ HIP_SYMBOLS = {
     "bsmr_plan_options_from_env": (C.c_int, [C.POINTER(PlanOptions)]),
     "bsmr_plan_destroy": (C.c_int, [C.c_void_p]),
     "bsmr_plan_promoted_on_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "bsmr_col_reorder_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "bsmr_plan_create_from_colreorder": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint32,
+                                                   C.c_void_p]),
     "bsmr_plan_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
     "bsmr_plan_build_times": (C.c_int, [C.c_void_p, C.POINTER(PlanBuildMs)]),
     "bsmr_plan_format_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -172,13 +172,11 @@ RPHM::RPHM(const sparseMatrix::CSR<float>& matrix, const BSMR& bsmr, int device)
     const size_t numBlocks = blockOffsets_.back();
     const size_t numSparse = sparseValueOffsets_.empty() ? 0 : sparseValueOffsets_.back();
     const BSMR::DeviceRphmArrays& fromDevice = bsmr.deviceRphm();
-    const bool useDeviceArrays = fromDevice.valid && fromDevice.blockOffsets == blockOffsets_ &&
-                                 fromDevice.blockValues.size() == numBlocks * BLOCK_SIZE && fromDevice.sparseValues.size() == numSparse;
+    const bool useDeviceArrays = fromDevice.valid && fromDevice.handle && fromDevice.blockOffsets == blockOffsets_ &&
+                                 fromDevice.numBlocks == numBlocks && fromDevice.numSparseEntries == numSparse;
     if (useDeviceArrays) {   // the column reordering ran on the device and produced the index arrays in the same pass
-        blockValues_ = fromDevice.blockValues;
-        sparseValues_ = fromDevice.sparseValues;
-        sparseRelativeRows_ = fromDevice.sparseRelativeRows;
-        sparseColIndices_ = fromDevice.sparseColIndices;
+        onDevice_ = fromDevice.handle;
+        if (device < 0) fetchBigArrays();
     } else {
     blockValues_.assign(numBlocks * BLOCK_SIZE, NULL_VALUE);
     sparseValues_.resize(numSparse);
@@ -232,13 +230,39 @@ RPHM::RPHM(const sparseMatrix::CSR<float>& matrix, const BSMR& bsmr, int device)
         d.sparse_values = sparseValues_.data();
         d.sparse_relative_rows = sparseRelativeRows_.data();
         d.sparse_col_indices = sparseColIndices_.data();
-        planStatus_ = bsmr_plan_create(&plan_, device, &d);
+        int where = -1;
+        if (onDevice_ && bsmr_col_reorder_device(onDevice_.get(), &where) == BSMR_OK && where == device) {
+            // the plan from the arrays where the column reordering left them
+            planStatus_ = bsmr_plan_create_from_colreorder(&plan_, onDevice_.get(), d.M, d.N, d.nnz, d.reordered_rows, d.num_nonzero_rows, nullptr);
+        } else {
+            fetchBigArrays();
+            d.block_values = blockValues_.data();
+            d.sparse_values = sparseValues_.data();
+            d.sparse_relative_rows = sparseRelativeRows_.data();
+            d.sparse_col_indices = sparseColIndices_.data();
+            planStatus_ = bsmr_plan_create(&plan_, device, &d);
+        }
         if (planStatus_ != BSMR_OK) {
             fprintf(stderr, "RPHM: device plan creation failed: %s (%s)\n", bsmr_strerror(planStatus_),
                     bsmr_last_hip_error());
             plan_ = nullptr;
         }
     }
+}
+
+void RPHM::fetchBigArrays() const {
+    if (!onDevice_) return;
+    const std::shared_ptr<bsmr_colreorder> h = std::move(onDevice_);
+    onDevice_.reset();
+    bsmr_colreorder_sizes sz{};
+    if (bsmr_col_reorder_sizes(h.get(), &sz) != BSMR_OK) return;
+    blockValues_.resize(sz.num_blocks * BLOCK_SIZE);
+    sparseValues_.resize(sz.num_sparse_entries);
+    sparseRelativeRows_.resize(sz.num_sparse_entries);
+    sparseColIndices_.resize(sz.num_sparse_entries);
+    if (bsmr_col_reorder_fetch(h.get(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, blockValues_.data(), sparseValues_.data(),
+                               sparseRelativeRows_.data(), sparseColIndices_.data()) != BSMR_OK)
+        fprintf(stderr, "RPHM: fetching the device arrays failed: %s\n", bsmr_last_hip_error());
 }
 
 void RPHM::release() {
@@ -263,6 +287,7 @@ RPHM& RPHM::operator=(RPHM&& o) noexcept {
     denseCols_ = std::move(o.denseCols_);
     blockOffsets_ = std::move(o.blockOffsets_);
     blockValues_ = std::move(o.blockValues_);
+    onDevice_ = std::move(o.onDevice_);
     sparseValueOffsets_ = std::move(o.sparseValueOffsets_);
     sparseValues_ = std::move(o.sparseValues_);
     sparseRelativeRows_ = std::move(o.sparseRelativeRows_);
@@ -324,20 +349,20 @@ void forEachBlockDensity(const std::vector<UIN>& blockValues, F f) {
 float RPHM::calculateDenseBlockAverageDensity() const {
     float total = 0.0f;
     size_t blocks = 0;
-    forEachBlockDensity(blockValues_, [&](float d) { total += d; ++blocks; });
+    forEachBlockDensity(blockValues(), [&](float d) { total += d; ++blocks; });
     return blocks ? total / blocks : 0.0f;
 }
 
 std::pair<float, float> RPHM::calculateMaxMinDensity() const {
     float mx = 0.0f, mn = 1.0f;
     bool any = false;
-    forEachBlockDensity(blockValues_, [&](float d) { mx = std::max(mx, d); mn = std::min(mn, d); any = true; });
+    forEachBlockDensity(blockValues(), [&](float d) { mx = std::max(mx, d); mn = std::min(mn, d); any = true; });
     return any ? std::make_pair(mx, mn) : std::make_pair(0.0f, 0.0f);
 }
 
 std::pair<float, UIN> RPHM::calculateDensityMode() const {
     std::map<UIN, UIN> histogram;  // nnz in block -> number of blocks
-    forEachBlockDensity(blockValues_, [&](float d) { ++histogram[static_cast<UIN>(std::lround(d * BLOCK_SIZE))]; });
+    forEachBlockDensity(blockValues(), [&](float d) { ++histogram[static_cast<UIN>(std::lround(d * BLOCK_SIZE))]; });
     UIN bestNnz = 0, bestFreq = 0;
     for (const auto& kv : histogram)
         if (kv.second > bestFreq) { bestNnz = kv.first; bestFreq = kv.second; }

@@ -146,15 +146,16 @@ bool colReordering_device(const sparseMatrix::CSR<float>& matrix, const std::vec
     sparseColOffsets.resize(static_cast<size_t>(sz.num_row_panels) + 1);
     sparseDataOffsets.resize(static_cast<size_t>(sz.num_row_panels) + 1);
     rphm.blockOffsets.resize(static_cast<size_t>(sz.num_row_panels) + 1);
-    rphm.blockValues.resize(sz.num_blocks * BLOCK_SIZE);
-    rphm.sparseValues.resize(sz.num_sparse_entries);
-    rphm.sparseRelativeRows.resize(sz.num_sparse_entries);
-    rphm.sparseColIndices.resize(sz.num_sparse_entries);
+    // the column lists and the offsets come down; block values and the residue's arrays stay behind the handle
     const int fs = bsmr_col_reorder_fetch(h, denseCols.data(), denseColOffsets.data(), sparseCols.data(), sparseColOffsets.data(),
-                                          sparseDataOffsets.data(), rphm.blockOffsets.data(), rphm.blockValues.data(),
-                                          rphm.sparseValues.data(), rphm.sparseRelativeRows.data(), rphm.sparseColIndices.data());
-    bsmr_col_reorder_free(h);
-    if (fs != BSMR_OK) return false;
+                                          sparseDataOffsets.data(), rphm.blockOffsets.data(), nullptr, nullptr, nullptr, nullptr);
+    rphm.handle.reset(h, [](bsmr_colreorder* p) { bsmr_col_reorder_free(p); });
+    if (fs != BSMR_OK) {
+        rphm.handle.reset();
+        return false;
+    }
+    rphm.numBlocks = sz.num_blocks;
+    rphm.numSparseEntries = sz.num_sparse_entries;
     rphm.valid = true;
     rphm.deviceMs = sz.elapsed_ms;
     time = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -326,11 +326,20 @@ typedef struct bsmr_colreorder_sizes {
 int bsmr_col_reorder(bsmr_colreorder **out, int device, uint32_t rows, uint32_t cols, const uint32_t *row_offsets,
                      const uint32_t *col_indices, const uint32_t *reordered_rows, uint32_t num_reordered, float delta);
 int bsmr_col_reorder_sizes(const bsmr_colreorder *h, bsmr_colreorder_sizes *out);
+int bsmr_col_reorder_device(const bsmr_colreorder *h, int *device);   /* where the result lies */
 int bsmr_col_reorder_fetch(const bsmr_colreorder *h, uint32_t *dense_cols, uint32_t *dense_col_offsets,
                            uint32_t *sparse_cols, uint32_t *sparse_col_offsets, uint32_t *sparse_value_offsets,
                            uint32_t *block_offsets, uint32_t *block_values, uint32_t *sparse_values,
                            uint32_t *sparse_relative_rows, uint32_t *sparse_col_indices);
 int bsmr_col_reorder_free(bsmr_colreorder *h);
+/* The plan straight from a bsmr_col_reorder result, on its device: the RPHM's big arrays (block values, the residue) are
+ * read where they lie - the promotion rule and the device packer run on them - and only what host-side steps need comes
+ * down.  The plan is the one bsmr_plan_create_ex builds from the fetched arrays, byte for byte; plans that need the arrays
+ * on the host (engines other than the streaming one, layouts of the host packer, k_hint) fetch them and take that road.
+ * reordered_rows as given to bsmr_col_reorder; options == NULL: bsmr_plan_options_from_env. */
+int bsmr_plan_create_from_colreorder(bsmr_plan **out, const bsmr_colreorder *h, uint32_t M, uint32_t N, uint32_t nnz,
+                                     const uint32_t *reordered_rows, uint32_t num_nonzero_rows,
+                                     const bsmr_plan_options *options);
 
 /* How the sparse residue of a call (K, compute_mode) will run: lanes that share one entry's
  * K-long dot product (the fp32 summation order of the residue depends on it; the CPU twin in

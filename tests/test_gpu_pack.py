@@ -185,3 +185,76 @@ def test_device_promotion_equals_the_host_rule(engine, oracle, name):
     finally:
         for plan in plans.values():
             engine.plan_destroy(plan)
+
+
+RESIDENT_CASES = {
+    "mycielskian13_promoted": (lambda: synth.mycielskian_pattern(k=13), 0.3, 0.3, {}),
+    "nips_all_dense": (lambda: synth.nips_like(), 0.3, 0.0, {}),
+    "nips_hybrid_as_rphm": (lambda: synth.nips_like(), 0.3, 0.3, {"promote_average": 0, "fold_dense_below": 0}),
+    "nips_hybrid_partly": (lambda: synth.nips_like(), 0.3, 0.3, {"promote_average": 24}),
+    "wathen_all_residue": (lambda: synth.wathen_pattern(nx=40, ny=40), 0.3, 0.3, {}),
+    "small_dense_part_folded": (lambda: synth.nips_like(rows=400, cols=3000, nnz=30000, seed=2), 0.3, 0.3, {}),
+    "bernoulli_tuned_engine": (lambda: synth.bernoulli(rows=1024, cols=2048, density=0.1, seed=9), 0.3, 0.0, {"dense_engine": 3}),
+    "bernoulli_second_format": (lambda: synth.bernoulli(rows=2048, cols=2048, density=0.1, seed=4), 0.3, 0.1, {}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(RESIDENT_CASES))
+def test_plan_from_the_device_arrays_of_the_column_reordering(engine, oracle, name):
+    """bsmr_plan_create_from_colreorder (the RPHM's big arrays stay where bsmr_col_reorder left them) builds the plan that
+    bsmr_plan_create_ex builds from the fetched arrays: format digest, statistics, dense flags, results bit for bit - on the
+    resident road (promotion and packing on the device) and on every road back to the host (folding, an engine that keeps
+    the dense entries on the host, the second format, a plan without blocks)."""
+    make, alpha, delta, options = RESIDENT_CASES[name]
+    rows, cols, ro, ci = make()
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    rr = np.ascontiguousarray(engine.Pipeline(csr, alpha=alpha, delta=delta, device=-1).array("reorderedRows"), dtype=np.uint32)
+    ro32, ci32 = np.ascontiguousarray(ro, dtype=np.uint32), np.ascontiguousarray(ci, dtype=np.uint32)
+    hip = engine.hip()
+    u32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+    h = C.c_void_p()
+    assert hip.bsmr_col_reorder(C.byref(h), 0, rows, cols, u32(ro32), u32(ci32), u32(rr), rr.size, delta) == engine.OK
+    opts = engine.plan_options(pack_on_device=1, promote_on_device=1, **options)
+    plans = {}
+    try:
+        resident = C.c_void_p()
+        assert hip.bsmr_plan_create_from_colreorder(C.byref(resident), h, rows, cols, csr.nnz, u32(rr), rr.size, C.byref(opts)) == engine.OK
+        plans["resident"] = resident
+        st, arrays, _ = engine.col_reorder_device(rows, cols, ro, ci, rr, delta)
+        assert st == engine.OK
+        arrays["reorderedRows"] = rr
+        st, plan = engine.plan_from_arrays(rows, cols, csr.nnz, arrays, device=0,
+                                           options=engine.plan_options(pack_on_device=1, promote_on_device=0, **options))
+        assert st == engine.OK
+        plans["fetched"] = plan
+        assert _digest(engine, plans["resident"]) == _digest(engine, plans["fetched"])
+        a, b = engine.PlanStats(), engine.PlanStats()
+        assert hip.bsmr_plan_get_stats(plans["fetched"], a) == engine.OK and hip.bsmr_plan_get_stats(plans["resident"], b) == engine.OK
+        for field, _ in engine.PlanStats._fields_:
+            assert getattr(a, field) == getattr(b, field), field
+        yes = C.c_int(-1)
+        assert hip.bsmr_plan_promoted_on_device(plans["resident"], C.byref(yes)) == engine.OK
+        print(f"{name}: dense blocks {a.num_dense_blocks}, residue {a.num_sparse_entries}, promoted {a.promoted_sparse_entries}, "
+              f"folded {a.folded_dense_entries}, promotion on the device: {yes.value}")
+        if name in ("mycielskian13_promoted", "nips_hybrid_partly"):
+            assert yes.value == 1 and a.promoted_sparse_entries > 0
+        K = 64
+        A, B = engine.make_data(rows * K, 5489), engine.make_data(cols * K, 5490)
+        dev = torch.device("cuda:0")
+        tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+        got = {}
+        for where, plan in plans.items():
+            f = np.zeros(csr.nnz, dtype=np.uint8)
+            assert hip.bsmr_plan_dense_flags(plan, f.ctypes.data_as(C.c_void_p)) == engine.OK
+            tP = torch.full((csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+            engine.sddmm(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
+            torch.cuda.synchronize()
+            got[where] = (f, tP.cpu().numpy())
+        assert np.array_equal(got["resident"][0], got["fetched"][0])
+        assert np.array_equal(got["resident"][1].view(np.uint32), got["fetched"][1].view(np.uint32))
+        bad, first = oracle.check_data(oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B), got["resident"][1])
+        assert bad == 0, (bad, first)
+    finally:
+        for plan in plans.values():
+            engine.plan_destroy(plan)
+        hip.bsmr_col_reorder_free(h)
