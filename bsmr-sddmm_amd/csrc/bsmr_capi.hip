@@ -2897,7 +2897,7 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
             if (!dev.alloc(&dReps, (size_t)active * numBins, "hipMalloc(representatives)")) return BSMR_ERR_OOM;
             // nothing in flight: the first pass judges nothing and seeds the first clusters at scanPos
             state.scanPos = firstNonEmpty;
-            state.tentative = (uint32_t)std::max(0, std::min(envInt("BSMR_CLUSTER_TENTATIVE", 1), (int)active));
+            state.tentative = (uint32_t)std::max(0, std::min(envInt("BSMR_CLUSTER_TENTATIVE", (int)bsmr::kClusterSpeculateFrom), (int)active));
             state.freeReps = active >= 32 ? 0xFFFFFFFFu : (1u << active) - 1u;
             BSMR_HIP(hipMemcpyAsync(dOrder, order.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
             BSMR_HIP(hipMemcpyAsync(dCluster, cluster.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
