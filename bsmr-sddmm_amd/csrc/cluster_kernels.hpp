@@ -86,6 +86,8 @@ struct ClusterState {
                          // none: only seeds that are certain) after a pass in which one was dropped
     uint32_t ahead;      // statistics: passes in which the clusters ran ahead of the older ones' decisions
     uint32_t startChunk; // first chunk of a new cluster: running mean of the chunks finished clusters ended with
+    uint32_t totalItems; // what the next pass judges, all clusters together (a workgroup without an item leaves before it loads the slots:
+                         // 512 workgroups reading the same 2 KB were a hot spot in one L2 channel)
     ClusterSlot slot[kClusterMaxActive];
 };
 
@@ -231,6 +233,10 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
     const uint32_t freeRepsIn = state->freeReps, startChunkIn = state->startChunk;
     const uint32_t passesIn = state->passes, aheadIn = state->ahead, droppedIn = state->dropped;
     const bool speculate = tentativeIn >= kClusterSpeculateFrom;
+    {
+        const uint32_t itemsIn = state->totalItems;
+        if (blockIdx.x >= (itemsIn ? itemsIn : 1u)) return;  // nothing to judge, and nobody waits for this workgroup
+    }
     if (threadIdx.x < active) {  // one slot per lane: one round trip
         const ClusterSlot c = state->slot[threadIdx.x];
         sSlot[threadIdx.x] = c;
@@ -709,6 +715,7 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
             sSlot[j].len = len;
             sSlot[j].start = upTo - len;
         }
+        if (j + 1 == left || (left == 0 && j == 0)) shared[3] = left ? upTo : 0u;
     }
     __syncthreads();
     if (threadIdx.x < left) state->slot[threadIdx.x] = sSlot[threadIdx.x];
@@ -723,6 +730,7 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
         state->dropped = droppedIn + dropped;
         state->tentative = tentative;
         state->startChunk = startChunk;
+        state->totalItems = shared[3];
         state->done = left == 0 && scanPos >= rows ? 1u : 0u;
     }
 }
