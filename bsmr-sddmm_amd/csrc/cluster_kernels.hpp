@@ -71,6 +71,19 @@ struct ClusterSlot {
                          // until it has (the representative does not change meanwhile, so the verdict stands)
 };
 
+// field by field, so that a slot held by a thread lives in registers (a whole-struct copy makes the compiler keep the struct in
+// memory - it then put one per thread into LDS, 60 KB per workgroup, and every field access went there)
+__device__ __forceinline__ ClusterSlot loadSlot(const ClusterSlot& s) {
+    ClusterSlot c;
+    c.seed = s.seed; c.cursor = s.cursor; c.chunk = s.chunk; c.id = s.id; c.sq = s.sq; c.total = s.total; c.firstHit = s.firstHit;
+    c.rep = s.rep; c.confirmed = s.confirmed; c.seedRow = s.seedRow; c.len = s.len; c.start = s.start; c.parked = s.parked;
+    return c;
+}
+__device__ __forceinline__ void storeSlot(ClusterSlot& d, const ClusterSlot& c) {
+    d.seed = c.seed; d.cursor = c.cursor; d.chunk = c.chunk; d.id = c.id; d.sq = c.sq; d.total = c.total; d.firstHit = c.firstHit;
+    d.rep = c.rep; d.confirmed = c.confirmed; d.seedRow = c.seedRow; d.len = c.len; d.start = c.start; d.parked = c.parked;
+}
+
 struct ClusterState {
     uint32_t numActive;  // slots [0, numActive), oldest first
     uint32_t nextId;     // id of the youngest seed
@@ -89,6 +102,9 @@ struct ClusterState {
     uint32_t totalItems; // what the next pass judges, all clusters together (a workgroup without an item leaves before it loads the slots:
                          // 512 workgroups reading the same 2 KB were a hot spot in one L2 channel)
     ClusterSlot slot[kClusterMaxActive];
+#ifdef BSMR_LAB_STAMPS
+    unsigned long long stamps[10];   // lab build: cycles of the closing workgroup per phase, summed over the passes
+#endif
 };
 
 // does bin b take part in the reference's block-wide sums?  liveWarps: bit w = warp w reaches the
@@ -206,6 +222,12 @@ __global__ void clusterPositionInfo(const uint32_t* __restrict__ order, const ui
 }
 
 // posInfo / encWords: MANY only.  encWords[i] = bin << 16 | count of the i-th nonzero bin (bins ascending inside a row).
+#ifdef BSMR_LAB_STAMPS
+#define CLUSTER_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now = __builtin_readcyclecounter(); labT[k] = now; } } while (0)
+#else
+#define CLUSTER_STAMP(k) do { } while (0)
+#endif
+
 template <bool MANY>
 __global__ void __launch_bounds__(1024, MANY ? 8 : 4)
 clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__ rowSquares,
@@ -225,6 +247,10 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
     // MANY only: items of this round within 1e-4 of alpha, (cluster << 27) | offset in its window
     __shared__ uint32_t sNear[MANY ? 1024 : 1];
     __shared__ uint32_t sNearCount;
+#ifdef BSMR_LAB_STAMPS
+    unsigned long long labT[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    CLUSTER_STAMP(0);
     if (state->done) return;  // uniform over the grid: the state only changes at the end of a pass
     const uint32_t active = state->numActive;
     const uint32_t T = blockDim.x;
@@ -238,8 +264,8 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
         if (blockIdx.x >= (itemsIn ? itemsIn : 1u)) return;  // nothing to judge, and nobody waits for this workgroup
     }
     if (threadIdx.x < active) {  // one slot per lane: one round trip
-        const ClusterSlot c = state->slot[threadIdx.x];
-        sSlot[threadIdx.x] = c;
+        const ClusterSlot c = loadSlot(state->slot[threadIdx.x]);
+        storeSlot(sSlot[threadIdx.x], c);
         sCursor[threadIdx.x] = c.cursor;
         sLen[threadIdx.x] = c.len;
         sStart[threadIdx.x] = c.start;
@@ -250,6 +276,7 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
         if (active == 0) sStart[0] = 0;
     }
     __syncthreads();
+    CLUSTER_STAMP(1);
     const uint32_t total = sStart[active];
     // one item per wave and round; the wave's lanes share the row's (bin, count) list
     const uint32_t wavesPerWG = (T + 63u) >> 6;
@@ -409,6 +436,7 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
         if (judged) atomicAdd(&shared[2], judged);
         __syncthreads();
     }
+    CLUSTER_STAMP(2);
     if (threadIdx.x == 0) {
         if (MANY && shared[2]) atomicAdd(&state->judged, shared[2]);
         if (exact) atomicAdd(&state->exact, exact);
@@ -418,6 +446,7 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
     __syncthreads();
     if (!shared[0]) return;
     __threadfence();
+    CLUSTER_STAMP(3);
 
     // 1. decisions, oldest cluster first.  Lane j of the first wave holds cluster j; the loop over the clusters reads the
     //    one it is at with v_readlane, so nothing but registers is touched (a single thread walking the slots in LDS
@@ -435,101 +464,173 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
         }
     }
     __syncthreads();
+    CLUSTER_STAMP(8);
     if (threadIdx.x < 32u) {
         const uint32_t j = threadIdx.x;
         const bool mine = j < active;
-        ClusterSlot c = sSlot[mine ? j : 0u];
+        ClusterSlot c = loadSlot(sSlot[mine ? j : 0u]);
         const uint32_t myHit = mine ? sHit[j] : kNoCluster, myLen = mine ? sLen[j] : 0u, myStart = mine ? sCursor[j] : 0u;
         const uint32_t myAssigned = mine ? sNew[j] : 0u;
-        // which older clusters accepted (in this pass) the row I accepted / my seed?
+        // which older clusters have (in this pass) a hit on the row I accepted / on my seed?
+        const uint32_t hitLanes = (uint32_t)__ballot(mine && myHit != kNoCluster);
         uint32_t sameHit = 0, seedHit = 0;
-        for (uint32_t i = 0; i < active; ++i) {
+        for (uint32_t todo = hitLanes; todo; todo &= todo - 1u) {
+            const uint32_t i = (uint32_t)__builtin_ctz(todo);
             const uint32_t h = __builtin_amdgcn_readlane(myHit, i);
-            if (i < j && h != kNoCluster) {
+            if (i < j) {
                 if (h == myHit) sameHit |= 1u << i;
                 if (h == c.seed) seedHit |= 1u << i;
             }
         }
-        // A confirmed cluster without a hit moves on by itself.  The others are walked in order, oldest first: what an
-        // older cluster decides (its new cursor, the row it takes) bears on the younger ones.
-        const bool walked = mine && (myHit != kNoCluster || !c.confirmed);
-        if (mine && !walked && myLen) {
-            c.cursor = myStart + myLen;
-            if (myLen == c.chunk) c.chunk = 4u * c.chunk > maxChunk ? maxChunk : 4u * c.chunk;
-        }
-        // smallest cursor among the older clusters that are not walked (exclusive prefix minimum over the lanes)
-        uint32_t olderMin = mine && !walked ? c.cursor : 0xFFFFFFFFu;
-        for (uint32_t w = 1; w < 32u; w <<= 1) {
-            const uint32_t other = __shfl_up(olderMin, w, 32);
-            if (j >= w) olderMin = olderMin < other ? olderMin : other;
-        }
-        olderMin = __shfl_up(olderMin, 1, 32);
-        if (j == 0) olderMin = 0xFFFFFFFFu;
-        uint32_t walkedMin = rows, freeReps = freeRepsIn, dropped = 0, accepted = 0;   // uniform over the lanes
+        uint32_t freeReps = freeRepsIn, dropped = 0, accepted = 0;   // uniform over the lanes
         uint32_t myAccept = kNoCluster, myDrop = 0, myFirstMerge = 0, myConfirmNow = 0;
-        for (uint32_t todo = (uint32_t)__ballot(walked); todo; todo &= todo - 1u) {
-            const uint32_t k = (uint32_t)__builtin_ctz(todo);
-            const uint32_t older = __builtin_amdgcn_readlane(olderMin, k);
-            const uint32_t decided = older < walkedMin ? older : walkedMin;   // every older cluster's cursor is at least here
-            const uint32_t seed = __builtin_amdgcn_readlane(c.seed, k), hit = __builtin_amdgcn_readlane(myHit, k);
-            const uint32_t start = __builtin_amdgcn_readlane(myStart, k), len = __builtin_amdgcn_readlane(myLen, k);
-            const uint32_t parked = __builtin_amdgcn_readlane(c.parked, k), assigned = __builtin_amdgcn_readlane(myAssigned, k);
-            const uint32_t hitTaken = __builtin_amdgcn_readlane(sameHit, k) & accepted, seedTaken = __builtin_amdgcn_readlane(seedHit, k) & accepted;
-            uint32_t confirmed = __builtin_amdgcn_readlane(c.confirmed, k), cursor = __builtin_amdgcn_readlane(c.cursor, k);
-            uint32_t chunk = __builtin_amdgcn_readlane(c.chunk, k), rep = __builtin_amdgcn_readlane(c.rep, k);
-            uint32_t nowParked = parked, accept = kNoCluster, drop = 0, firstMerge = 0, confirmNow = 0;
-            if (!confirmed) {
-                if (seedTaken) {
-                    drop = 1;
-                    ++dropped;
-                } else if (decided > seed) {
-                    confirmed = 1;
-                    confirmNow = 1;
-                }
+        if (!speculate && (uint32_t)__ballot(mine && (c.parked || (!c.confirmed && myHit != kNoCluster))) == 0u) {
+            // Nobody ran ahead in this pass: every hit lies behind the older clusters' cursors and can be taken at once - by the
+            // oldest cluster that has it - and no unconfirmed cluster has a hit.  One step for all lanes, no walk.
+            const bool hasHit = mine && myHit != kNoCluster;
+            const bool takes = hasHit && sameHit == 0u && c.confirmed;
+            accepted = (uint32_t)__ballot(takes);
+            if (hasHit) {
+                // judging costs time even beside the hit, so the next pass looks twice as far as this hit was
+                const uint32_t gap = 2u * (myHit - myStart + 1u);
+                c.chunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
+                c.cursor = myHit + 1u;
+                if (takes) myAccept = myHit;
+            } else if (mine && myLen) {
+                c.cursor = myStart + myLen;
+                if (myLen == c.chunk && c.confirmed) c.chunk = 4u * c.chunk > maxChunk ? maxChunk : 4u * c.chunk;
             }
-            if (!drop) {
-                if (hit != kNoCluster) {
-                    // judging costs time even beside the hit, so the next pass looks twice as far as this hit was
-                    if (!parked) {
-                        const uint32_t gap = 2u * (hit - start + 1u);
-                        chunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
+            const uint32_t needs = (uint32_t)__ballot(takes && c.rep == kClusterOwnRow);   // first merges: one free buffer each, in order
+            if (takes && c.rep == kClusterOwnRow) {
+                uint32_t f = freeRepsIn;
+                for (uint32_t n = __popc(needs & ((1u << j) - 1u)); n; --n) f &= f - 1u;
+                c.rep = (uint32_t)__builtin_ctz(f);
+                myFirstMerge = 1;
+            }
+            for (uint32_t n = __popc(needs); n; --n) freeReps &= freeReps - 1u;
+            if (mine && !c.confirmed && (seedHit & accepted)) myDrop = 1;   // an older cluster took the seed
+            uint32_t olderMin = mine && !myDrop ? c.cursor : 0xFFFFFFFFu;   // exclusive prefix minimum of the new cursors
+            for (uint32_t w = 1; w < 32u; w <<= 1) {
+                const uint32_t other = __shfl_up(olderMin, w, 32);
+                if (j >= w) olderMin = olderMin < other ? olderMin : other;
+            }
+            olderMin = __shfl_up(olderMin, 1, 32);
+            if (j == 0) olderMin = 0xFFFFFFFFu;
+            if (mine && !c.confirmed && !myDrop && olderMin > c.seed) {
+                c.confirmed = 1;
+                myConfirmNow = 1;
+            }
+            dropped = __popc((uint32_t)__ballot(myDrop != 0u));
+        } else {
+            // A cluster without a hit moves on by itself.  Those with a hit are walked in order, oldest first: what an older
+            // cluster decides (its new cursor, the row it takes) bears on the younger ones.  Whether the unconfirmed ones
+            // among the others are confirmed or dropped follows from the cursors and the rows taken, for all lanes at once.
+            const bool hasHit = mine && myHit != kNoCluster;
+            if (mine && !hasHit && myLen) {
+                c.cursor = myStart + myLen;
+                // (a tentative cluster looks no further per pass than it did at first: what it judges may be for nothing)
+                if (myLen == c.chunk && c.confirmed) c.chunk = 4u * c.chunk > maxChunk ? maxChunk : 4u * c.chunk;
+            }
+            // smallest cursor among the older clusters whose new cursor is known already (exclusive prefix minimum over the lanes)
+            auto olderMinimum = [&](uint32_t mineOrNone) {
+                uint32_t m = mineOrNone;
+                for (uint32_t w = 1; w < 32u; w <<= 1) {
+                    const uint32_t other = __shfl_up(m, w, 32);
+                    if (j >= w) m = m < other ? m : other;
+                }
+                m = __shfl_up(m, 1, 32);
+                return j == 0 ? 0xFFFFFFFFu : m;
+            };
+            uint32_t olderMin = olderMinimum(mine && !hasHit ? c.cursor : 0xFFFFFFFFu);
+            // a parked cluster stays parked as long as one of those cursors is not behind its row (the clusters walked below can
+            // only bring the bound down further): no need to walk it - with many clusters waiting, walking them was most of the
+            // decisions' time.  (If an older cluster takes the row in this very pass, the next pass sees that.)
+            const bool stays = hasHit && c.parked && !myAssigned && olderMin <= myHit;
+            const bool walked = hasHit && !stays;
+            if ((uint32_t)__ballot(stays) != 0u) olderMin = olderMinimum(mine && !walked ? c.cursor : 0xFFFFFFFFu);
+            uint32_t walkedMin = rows;   // uniform over the lanes
+            for (uint32_t todo = (uint32_t)__ballot(walked); todo; todo &= todo - 1u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(todo);
+                const uint32_t older = __builtin_amdgcn_readlane(olderMin, k);
+                const uint32_t decided = older < walkedMin ? older : walkedMin;   // every older cluster's cursor is at least here
+                const uint32_t seed = __builtin_amdgcn_readlane(c.seed, k), hit = __builtin_amdgcn_readlane(myHit, k);
+                const uint32_t start = __builtin_amdgcn_readlane(myStart, k), len = __builtin_amdgcn_readlane(myLen, k);
+                const uint32_t parked = __builtin_amdgcn_readlane(c.parked, k), assigned = __builtin_amdgcn_readlane(myAssigned, k);
+                const uint32_t hitTaken = __builtin_amdgcn_readlane(sameHit, k) & accepted, seedTaken = __builtin_amdgcn_readlane(seedHit, k) & accepted;
+                uint32_t confirmed = __builtin_amdgcn_readlane(c.confirmed, k), cursor = __builtin_amdgcn_readlane(c.cursor, k);
+                uint32_t chunk = __builtin_amdgcn_readlane(c.chunk, k), rep = __builtin_amdgcn_readlane(c.rep, k);
+                uint32_t nowParked = parked, accept = kNoCluster, drop = 0, firstMerge = 0, confirmNow = 0;
+                if (!confirmed) {
+                    if (seedTaken) {
+                        drop = 1;
+                        ++dropped;
+                    } else if (decided > seed) {
+                        confirmed = 1;
+                        confirmNow = 1;
                     }
-                    if (hitTaken || (parked && assigned)) {  // somebody older has it
-                        cursor = hit + 1;
-                        nowParked = 0;
-                    } else if (confirmed && hit < decided) {  // every older cluster has passed over it
-                        nowParked = 0;
-                        accept = hit;
-                        accepted |= 1u << k;
-                        cursor = hit + 1;
-                        if (rep == kClusterOwnRow) {
-                            rep = (uint32_t)__builtin_ctz(freeReps);
-                            freeReps &= freeReps - 1u;
-                            firstMerge = 1;
+                }
+                if (!drop) {
+                    if (hit != kNoCluster) {
+                        // judging costs time even beside the hit, so the next pass looks twice as far as this hit was
+                        if (!parked) {
+                            const uint32_t gap = 2u * (hit - start + 1u);
+                            chunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
                         }
-                    } else {  // an older cluster has not decided that position yet: wait in front of it
-                        cursor = hit;
-                        nowParked = 1;
+                        if (hitTaken || (parked && assigned)) {  // somebody older has it
+                            cursor = hit + 1;
+                            nowParked = 0;
+                        } else if (confirmed && hit < decided) {  // every older cluster has passed over it
+                            nowParked = 0;
+                            accept = hit;
+                            accepted |= 1u << k;
+                            cursor = hit + 1;
+                            if (rep == kClusterOwnRow) {
+                                rep = (uint32_t)__builtin_ctz(freeReps);
+                                freeReps &= freeReps - 1u;
+                                firstMerge = 1;
+                            }
+                        } else {  // an older cluster has not decided that position yet: wait in front of it
+                            cursor = hit;
+                            nowParked = 1;
+                        }
+                    } else if (len) {
+                        // (a tentative cluster looks no further per pass than it did at first: what it judges may be for nothing)
+                        cursor = start + len;
+                        if (len == chunk && confirmed) chunk = 4u * chunk > maxChunk ? maxChunk : 4u * chunk;
                     }
-                } else if (len) {
-                    // (a tentative cluster looks no further per pass than it did at first: what it judges may be for nothing)
-                    cursor = start + len;
-                    if (len == chunk && confirmed) chunk = 4u * chunk > maxChunk ? maxChunk : 4u * chunk;
+                    walkedMin = walkedMin < cursor ? walkedMin : cursor;
                 }
-                walkedMin = walkedMin < cursor ? walkedMin : cursor;
+                if (j == k) {
+                    c.confirmed = confirmed;
+                    c.cursor = cursor;
+                    c.chunk = chunk;
+                    c.rep = rep;
+                    c.parked = nowParked;
+                    myAccept = accept;
+                    myDrop = drop;
+                    myFirstMerge = firstMerge;
+                    myConfirmNow = confirmNow;
+                }
             }
-            if (j == k) {
-                c.confirmed = confirmed;
-                c.cursor = cursor;
-                c.chunk = chunk;
-                c.rep = rep;
-                c.parked = nowParked;
-                myAccept = accept;
-                myDrop = drop;
-                myFirstMerge = firstMerge;
-                myConfirmNow = confirmNow;
+            // the unconfirmed clusters that had no hit: dropped when an older cluster took the seed in this pass, confirmed
+            // when every older cluster that stays has its cursor behind the seed
+            if (mine && !walked && !c.confirmed && (seedHit & accepted)) {
+                myDrop = 1;
+            }
+            dropped += __popc((uint32_t)__ballot(mine && !walked && myDrop != 0u));
+            uint32_t olderAll = mine && !myDrop ? c.cursor : 0xFFFFFFFFu;
+            for (uint32_t w = 1; w < 32u; w <<= 1) {
+                const uint32_t other = __shfl_up(olderAll, w, 32);
+                if (j >= w) olderAll = olderAll < other ? olderAll : other;
+            }
+            olderAll = __shfl_up(olderAll, 1, 32);
+            if (j == 0) olderAll = 0xFFFFFFFFu;
+            if (mine && !walked && !c.confirmed && !myDrop && olderAll > c.seed) {
+                c.confirmed = 1;
+                myConfirmNow = 1;
             }
         }
+        CLUSTER_STAMP(9);
         c.firstHit = kNoCluster;
         // 2. dropped and finished clusters leave (a tentative cluster that has judged everything waits for its confirmation)
         const bool finished = mine && !myDrop && c.confirmed && c.cursor >= rows;
@@ -544,8 +645,9 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
             if (myAccept != kNoCluster) {
                 cluster[myAccept] = c.id;
                 sNew[j] = order[myAccept];   // the row to merge (all of them fetched at once)
+                sHit[__popc(accepted & ((1u << j) - 1u))] = j;   // (the hits are in registers by now: the list of clusters that merge)
             }
-            sSlot[j] = c;   // (moved to its place after the merges, which read rep and seedRow by the old index)
+            storeSlot(sSlot[j], c);   // (moved to its place after the merges, which read rep and seedRow by the old index)
         }
         // the first chunk of the next clusters: running mean over the finished ones (any order)
         uint32_t startChunk = startChunkIn, minCursor = keep ? c.cursor : rows;
@@ -569,33 +671,86 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
             sStart[2] = startChunk < 2u * kClusterMinChunk ? 2u * kClusterMinChunk : (startChunk > maxChunk ? maxChunk : startChunk);
             sStart[3] = __popc(accepted);
             sStart[4] = __popc((uint32_t)__ballot(mine && myLen > 0));
+            sStart[5] = __popc(accepted);
         }
     }
     __syncthreads();
+    CLUSTER_STAMP(4);
     // 3. merges: every accepted row is added to its cluster's representative.  The clusters are independent
     //    here, so all merges run in one sweep (per-cluster sums: a wave adds its lanes up and issues one LDS atomic)
-    for (uint32_t j = 0; j < active; ++j) {
-        const uint32_t hit = sAccept[j];
-        if (hit == kNoCluster) continue;  // uniform
-        uint32_t* rep = reps + (size_t)sSlot[j].rep * numBins;
-        const ClusterCount* add = table + (size_t)sNew[j] * numBins;
-        const ClusterCount* own = sFirstMerge[j] ? ownRow(j) : nullptr;
-        uint32_t sq = 0, tot = 0;
-        for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
-            const uint32_t v = (own ? (uint32_t)own[i] : rep[i]) + (uint32_t)add[i];
-            rep[i] = v;
-            if (binCounts(i, blockDim.x, liveWarps)) {
-                sq += v * v;
-                tot += v;
+    const uint32_t merging = sStart[5];
+    // (a thread's bins are threadIdx.x, threadIdx.x + T, ...: bin % T is the thread's number, so whether its bins take part in
+    // the reference's block-wide sums is one bit per thread, not a modulo per bin)
+    const bool myBinsCount = (liveWarps >> (threadIdx.x >> 5)) & 1u;
+    if ((numBins + T - 1u) / T <= 8u) {
+        // a thread owns at most eight bins of a representative: the loads of two merges are issued together, all of a thread's
+        // bins at once (one merge after the other, bin after bin, was the longest phase of a small pass)
+        for (uint32_t a0 = 0; a0 < merging; a0 += 2u) {  // uniform
+            uint32_t have[2][8], plus[2][8];
+#pragma unroll
+            for (uint32_t b = 0; b < 2u; ++b) {
+                if (a0 + b >= merging) break;  // uniform
+                const uint32_t j = sHit[a0 + b];
+                const uint32_t* rep = reps + (size_t)sSlot[j].rep * numBins;
+                const ClusterCount* add = table + (size_t)sNew[j] * numBins;
+                const ClusterCount* own = sFirstMerge[j] ? ownRow(j) : nullptr;
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k) {
+                    const uint32_t i = threadIdx.x + k * T;
+                    have[b][k] = i < numBins ? (own ? (uint32_t)own[i] : rep[i]) : 0u;
+                    plus[b][k] = i < numBins ? (uint32_t)add[i] : 0u;
+                }
+            }
+#pragma unroll
+            for (uint32_t b = 0; b < 2u; ++b) {
+                if (a0 + b >= merging) break;  // uniform
+                const uint32_t j = sHit[a0 + b];
+                uint32_t* rep = reps + (size_t)sSlot[j].rep * numBins;
+                uint32_t sq = 0, tot = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k) {
+                    const uint32_t i = threadIdx.x + k * T;
+                    if (i >= numBins) continue;
+                    const uint32_t v = have[b][k] + plus[b][k];
+                    rep[i] = v;
+                    if (myBinsCount) {
+                        sq += v * v;
+                        tot += v;
+                    }
+                }
+                for (uint32_t w = lanes >> 1; w >= 1; w >>= 1) {  // `lanes` = 32 in a block's last, half-filled wave
+                    sq += __shfl_xor(sq, w, 64);
+                    tot += __shfl_xor(tot, w, 64);
+                }
+                if ((threadIdx.x & 63u) == 0) {
+                    atomicAdd(&sSumSq[j], sq);
+                    atomicAdd(&sSumTotal[j], tot);
+                }
             }
         }
-        for (uint32_t w = lanes >> 1; w >= 1; w >>= 1) {  // `lanes` = 32 in a block's last, half-filled wave
-            sq += __shfl_xor(sq, w, 64);
-            tot += __shfl_xor(tot, w, 64);
-        }
-        if ((threadIdx.x & 63u) == 0) {
-            atomicAdd(&sSumSq[j], sq);
-            atomicAdd(&sSumTotal[j], tot);
+    } else {
+        for (uint32_t a = 0; a < merging; ++a) {  // uniform
+            const uint32_t j = sHit[a];
+            uint32_t* rep = reps + (size_t)sSlot[j].rep * numBins;
+            const ClusterCount* add = table + (size_t)sNew[j] * numBins;
+            const ClusterCount* own = sFirstMerge[j] ? ownRow(j) : nullptr;
+            uint32_t sq = 0, tot = 0;
+            for (uint32_t i = threadIdx.x; i < numBins; i += blockDim.x) {
+                const uint32_t v = (own ? (uint32_t)own[i] : rep[i]) + (uint32_t)add[i];
+                rep[i] = v;
+                if (myBinsCount) {
+                    sq += v * v;
+                    tot += v;
+                }
+            }
+            for (uint32_t w = lanes >> 1; w >= 1; w >>= 1) {  // `lanes` = 32 in a block's last, half-filled wave
+                sq += __shfl_xor(sq, w, 64);
+                tot += __shfl_xor(tot, w, 64);
+            }
+            if ((threadIdx.x & 63u) == 0) {
+                atomicAdd(&sSumSq[j], sq);
+                atomicAdd(&sSumTotal[j], tot);
+            }
         }
     }
     __syncthreads();
@@ -603,14 +758,14 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
         ClusterSlot c;
         const bool moves = threadIdx.x < active && sDrop[threadIdx.x] != 0xFFu;
         if (moves) {
-            c = sSlot[threadIdx.x];
+            c = loadSlot(sSlot[threadIdx.x]);
             if (sAccept[threadIdx.x] != kNoCluster) {
                 c.sq = sSumSq[threadIdx.x];
                 c.total = sSumTotal[threadIdx.x];
             }
         }
         __syncthreads();
-        if (moves) sSlot[sDrop[threadIdx.x]] = c;
+        if (moves) storeSlot(sSlot[sDrop[threadIdx.x]], c);
     }
     __syncthreads();
     uint32_t left = shared[0];
@@ -618,6 +773,7 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
     const uint32_t unconfirmed = sStart[0], confirmedNow = sStart[1], startChunk = sStart[2], hitsNow = sStart[3], judging = sStart[4];
     uint32_t tentative = tentativeIn;
     __syncthreads();
+    CLUSTER_STAMP(5);
     // 4. new clusters: the next positions without a cluster, in order.  The first of them is a cluster for certain when
     //    everything in flight has passed over it (round 2 seeded only those); beyond it, as many as may run unconfirmed.
     uint32_t scanPos = scanPosIn, numNew = 0;
@@ -683,10 +839,11 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
         c.parked = 0;
         c.confirmed = threadIdx.x == 0 && certain ? 1u : 0u;
         if (c.confirmed) cluster[u] = c.id;
-        sSlot[left + threadIdx.x] = c;
+        storeSlot(sSlot[left + threadIdx.x], c);
     }
     left += numNew;
     __syncthreads();
+    CLUSTER_STAMP(6);
     // 5. what the next pass judges.  Running ahead of the older clusters pays when most rows end up in clusters of their
     //    own (what a younger cluster judges early is then rarely taken away by an older one) and costs when clusters are
     //    large.  The number of clusters that may run unconfirmed measures exactly that; below kClusterSpeculateFrom a
@@ -718,7 +875,7 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
         if (j + 1 == left || (left == 0 && j == 0)) shared[3] = left ? upTo : 0u;
     }
     __syncthreads();
-    if (threadIdx.x < left) state->slot[threadIdx.x] = sSlot[threadIdx.x];
+    if (threadIdx.x < left) storeSlot(state->slot[threadIdx.x], loadSlot(sSlot[threadIdx.x]));
     if (threadIdx.x == 0) {
         state->numActive = left;
         state->nextId = nextId + numNew;
@@ -731,6 +888,13 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
         state->tentative = tentative;
         state->startChunk = startChunk;
         state->totalItems = shared[3];
+#ifdef BSMR_LAB_STAMPS
+        labT[7] = __builtin_readcyclecounter();
+        for (int k = 1; k <= 7; ++k) state->stamps[k] += labT[k] - labT[k - 1];
+        state->stamps[8] += labT[8] - labT[3];
+        state->stamps[9] += labT[9] - labT[8];
+        state->stamps[0] += 1;
+#endif
         state->done = left == 0 && scanPos >= rows ? 1u : 0u;
     }
 }
