@@ -551,65 +551,53 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
             uint32_t walkedMin = rows;   // uniform over the lanes
             for (uint32_t todo = (uint32_t)__ballot(walked); todo; todo &= todo - 1u) {
                 const uint32_t k = (uint32_t)__builtin_ctz(todo);
-                const uint32_t older = __builtin_amdgcn_readlane(olderMin, k);
-                const uint32_t decided = older < walkedMin ? older : walkedMin;   // every older cluster's cursor is at least here
-                const uint32_t seed = __builtin_amdgcn_readlane(c.seed, k), hit = __builtin_amdgcn_readlane(myHit, k);
-                const uint32_t start = __builtin_amdgcn_readlane(myStart, k), len = __builtin_amdgcn_readlane(myLen, k);
-                const uint32_t parked = __builtin_amdgcn_readlane(c.parked, k), assigned = __builtin_amdgcn_readlane(myAssigned, k);
-                const uint32_t hitTaken = __builtin_amdgcn_readlane(sameHit, k) & accepted, seedTaken = __builtin_amdgcn_readlane(seedHit, k) & accepted;
-                uint32_t confirmed = __builtin_amdgcn_readlane(c.confirmed, k), cursor = __builtin_amdgcn_readlane(c.cursor, k);
-                uint32_t chunk = __builtin_amdgcn_readlane(c.chunk, k), rep = __builtin_amdgcn_readlane(c.rep, k);
-                uint32_t nowParked = parked, accept = kNoCluster, drop = 0, firstMerge = 0, confirmNow = 0;
-                if (!confirmed) {
-                    if (seedTaken) {
-                        drop = 1;
-                        ++dropped;
-                    } else if (decided > seed) {
-                        confirmed = 1;
-                        confirmNow = 1;
-                    }
-                }
-                if (!drop) {
-                    if (hit != kNoCluster) {
-                        // judging costs time even beside the hit, so the next pass looks twice as far as this hit was
-                        if (!parked) {
-                            const uint32_t gap = 2u * (hit - start + 1u);
-                            chunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
-                        }
-                        if (hitTaken || (parked && assigned)) {  // somebody older has it
-                            cursor = hit + 1;
-                            nowParked = 0;
-                        } else if (confirmed && hit < decided) {  // every older cluster has passed over it
-                            nowParked = 0;
-                            accept = hit;
-                            accepted |= 1u << k;
-                            cursor = hit + 1;
-                            if (rep == kClusterOwnRow) {
-                                rep = (uint32_t)__builtin_ctz(freeReps);
-                                freeReps &= freeReps - 1u;
-                                firstMerge = 1;
-                            }
-                        } else {  // an older cluster has not decided that position yet: wait in front of it
-                            cursor = hit;
-                            nowParked = 1;
-                        }
-                    } else if (len) {
-                        // (a tentative cluster looks no further per pass than it did at first: what it judges may be for nothing)
-                        cursor = start + len;
-                        if (len == chunk && confirmed) chunk = 4u * chunk > maxChunk ? maxChunk : 4u * chunk;
-                    }
-                    walkedMin = walkedMin < cursor ? walkedMin : cursor;
-                }
+                // lane k decides for its cluster on its own registers; what the younger ones need of it - its new cursor, whether it
+                // took its row, was dropped, wants a buffer - is read back with v_readlane
+                uint32_t wantsRep = 0;
                 if (j == k) {
-                    c.confirmed = confirmed;
-                    c.cursor = cursor;
-                    c.chunk = chunk;
-                    c.rep = rep;
-                    c.parked = nowParked;
-                    myAccept = accept;
-                    myDrop = drop;
-                    myFirstMerge = firstMerge;
-                    myConfirmNow = confirmNow;
+                    const uint32_t decided = olderMin < walkedMin ? olderMin : walkedMin;   // every older cluster's cursor is at least here
+                    if (!c.confirmed) {
+                        if (seedHit & accepted) {
+                            myDrop = 1;
+                        } else if (decided > c.seed) {
+                            c.confirmed = 1;
+                            myConfirmNow = 1;
+                        }
+                    }
+                    if (!myDrop) {
+                        // judging costs time even beside the hit, so the next pass looks twice as far as this hit was
+                        if (!c.parked) {
+                            const uint32_t gap = 2u * (myHit - myStart + 1u);
+                            c.chunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
+                        }
+                        if ((sameHit & accepted) || (c.parked && myAssigned)) {  // somebody older has it
+                            c.cursor = myHit + 1u;
+                            c.parked = 0;
+                        } else if (c.confirmed && myHit < decided) {  // every older cluster has passed over it
+                            c.parked = 0;
+                            myAccept = myHit;
+                            c.cursor = myHit + 1u;
+                            wantsRep = c.rep == kClusterOwnRow ? 1u : 0u;
+                        } else {  // an older cluster has not decided that position yet: wait in front of it
+                            c.cursor = myHit;
+                            c.parked = 1;
+                        }
+                    }
+                }
+                const uint32_t cursorNow = __builtin_amdgcn_readlane(c.cursor, k), dropNow = __builtin_amdgcn_readlane(myDrop, k);
+                const uint32_t tookRow = __builtin_amdgcn_readlane(myAccept, k) != kNoCluster ? 1u : 0u;
+                if (dropNow) {
+                    ++dropped;
+                } else {
+                    walkedMin = walkedMin < cursorNow ? walkedMin : cursorNow;
+                    if (tookRow) accepted |= 1u << k;
+                    if (__builtin_amdgcn_readlane(wantsRep, k)) {   // first merge: the lowest free buffer
+                        if (j == k) {
+                            c.rep = (uint32_t)__builtin_ctz(freeReps);
+                            myFirstMerge = 1;
+                        }
+                        freeReps &= freeReps - 1u;
+                    }
                 }
             }
             // the unconfirmed clusters that had no hit: dropped when an older cluster took the seed in this pass, confirmed
