@@ -2982,10 +2982,12 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
             stats->threads_per_pair = T;
             stats->table_bytes = tableBytes;
 #ifdef BSMR_LAB_STAMPS
-            fprintf(stderr, "cluster stamps (100 MHz ticks per pass, closing workgroup): slots %.1f items %.1f arrive %.1f decisions %.1f merges %.1f seeding %.1f windows+store %.1f | of decisions: loads %.1f walk %.1f | over %llu passes\n",
+            fprintf(stderr, "cluster stamps (100 MHz ticks per pass, closing workgroup): slots %.1f items %.1f arrive %.1f decisions %.1f merges %.1f seeding %.1f windows+store %.1f | of decisions: loads %.1f walk %.1f (general path: load+hits %.1f prefix %.1f walk %.1f rest %.1f over %llu) | over %llu passes\n",
                     (double)state.stamps[1] / state.stamps[0], (double)state.stamps[2] / state.stamps[0], (double)state.stamps[3] / state.stamps[0],
                     (double)state.stamps[4] / state.stamps[0], (double)state.stamps[5] / state.stamps[0], (double)state.stamps[6] / state.stamps[0],
-                    (double)state.stamps[7] / state.stamps[0], (double)state.stamps[8] / state.stamps[0], (double)state.stamps[9] / state.stamps[0], state.stamps[0]);
+                    (double)state.stamps[7] / state.stamps[0], (double)state.stamps[8] / state.stamps[0], (double)state.stamps[9] / state.stamps[0],
+                    (double)state.stamps[10] / std::max(1ull, state.stamps[14]), (double)state.stamps[11] / std::max(1ull, state.stamps[14]),
+                    (double)state.stamps[12] / std::max(1ull, state.stamps[14]), (double)state.stamps[13] / std::max(1ull, state.stamps[14]), state.stamps[14], state.stamps[0]);
 #endif
             stats->dropped_seeds = state.dropped;
             stats->passes_ahead = state.ahead;

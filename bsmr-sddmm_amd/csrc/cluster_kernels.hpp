@@ -103,7 +103,7 @@ struct ClusterState {
                          // 512 workgroups reading the same 2 KB were a hot spot in one L2 channel)
     ClusterSlot slot[kClusterMaxActive];
 #ifdef BSMR_LAB_STAMPS
-    unsigned long long stamps[10];   // lab build: cycles of the closing workgroup per phase, summed over the passes
+    unsigned long long stamps[16];   // lab build: cycles of the closing workgroup per phase, summed over the passes
 #endif
 };
 
@@ -248,7 +248,7 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
     __shared__ uint32_t sNear[MANY ? 1024 : 1];
     __shared__ uint32_t sNearCount;
 #ifdef BSMR_LAB_STAMPS
-    unsigned long long labT[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long labT[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     CLUSTER_STAMP(0);
     if (state->done) return;  // uniform over the grid: the state only changes at the end of a pass
@@ -482,6 +482,7 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
                 if (h == c.seed) seedHit |= 1u << i;
             }
         }
+        CLUSTER_STAMP(10);
         uint32_t freeReps = freeRepsIn, dropped = 0, accepted = 0;   // uniform over the lanes
         uint32_t myAccept = kNoCluster, myDrop = 0, myFirstMerge = 0, myConfirmNow = 0;
         if (!speculate && (uint32_t)__ballot(mine && (c.parked || (!c.confirmed && myHit != kNoCluster))) == 0u) {
@@ -522,17 +523,19 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
             }
             dropped = __popc((uint32_t)__ballot(myDrop != 0u));
         } else {
-            // A cluster without a hit moves on by itself.  Those with a hit are walked in order, oldest first: what an older
-            // cluster decides (its new cursor, the row it takes) bears on the younger ones.  Whether the unconfirmed ones
-            // among the others are confirmed or dropped follows from the cursors and the rows taken, for all lanes at once.
+            // A cluster without a hit moves on by itself.  For one with a hit the question is whether every older cluster's cursor
+            // is behind the row.  The new cursor of an older cluster without a hit is known; that of one with a hit is its hit
+            // or one more.  So with L = the smallest of those (hits counted as they are): a hit below L can be taken - and the
+            // cluster confirmed on the way, L is then behind its seed too - and anything else waits in front of its row
+            // (also a row an older cluster takes in this very pass: the next pass sees it assigned).  No lane waits for
+            // another one's decision; waiting where a walk through the lanes would have found out more costs a pass at most.
             const bool hasHit = mine && myHit != kNoCluster;
             if (mine && !hasHit && myLen) {
                 c.cursor = myStart + myLen;
                 // (a tentative cluster looks no further per pass than it did at first: what it judges may be for nothing)
                 if (myLen == c.chunk && c.confirmed) c.chunk = 4u * c.chunk > maxChunk ? maxChunk : 4u * c.chunk;
             }
-            // smallest cursor among the older clusters whose new cursor is known already (exclusive prefix minimum over the lanes)
-            auto olderMinimum = [&](uint32_t mineOrNone) {
+            auto olderMinimum = [&](uint32_t mineOrNone) {   // exclusive prefix minimum over the lanes
                 uint32_t m = mineOrNone;
                 for (uint32_t w = 1; w < 32u; w <<= 1) {
                     const uint32_t other = __shfl_up(m, w, 32);
@@ -541,79 +544,48 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
                 m = __shfl_up(m, 1, 32);
                 return j == 0 ? 0xFFFFFFFFu : m;
             };
-            uint32_t olderMin = olderMinimum(mine && !hasHit ? c.cursor : 0xFFFFFFFFu);
-            // a parked cluster stays parked as long as one of those cursors is not behind its row (the clusters walked below can
-            // only bring the bound down further): no need to walk it - with many clusters waiting, walking them was most of the
-            // decisions' time.  (If an older cluster takes the row in this very pass, the next pass sees that.)
-            const bool stays = hasHit && c.parked && !myAssigned && olderMin <= myHit;
-            const bool walked = hasHit && !stays;
-            if ((uint32_t)__ballot(stays) != 0u) olderMin = olderMinimum(mine && !walked ? c.cursor : 0xFFFFFFFFu);
-            uint32_t walkedMin = rows;   // uniform over the lanes
-            for (uint32_t todo = (uint32_t)__ballot(walked); todo; todo &= todo - 1u) {
-                const uint32_t k = (uint32_t)__builtin_ctz(todo);
-                // lane k decides for its cluster on its own registers; what the younger ones need of it - its new cursor, whether it
-                // took its row, was dropped, wants a buffer - is read back with v_readlane
-                uint32_t wantsRep = 0;
-                if (j == k) {
-                    const uint32_t decided = olderMin < walkedMin ? olderMin : walkedMin;   // every older cluster's cursor is at least here
+            const uint32_t bound = olderMinimum(!mine ? 0xFFFFFFFFu : (hasHit ? myHit : c.cursor));
+            CLUSTER_STAMP(11);
+            bool takes = false;
+            if (hasHit) {
+                // judging costs time even beside the hit, so the next pass looks twice as far as this hit was
+                if (!c.parked) {
+                    const uint32_t gap = 2u * (myHit - myStart + 1u);
+                    c.chunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
+                }
+                if (c.parked && myAssigned) {  // somebody older took it meanwhile
+                    c.cursor = myHit + 1u;
+                    c.parked = 0;
+                } else if (myHit < bound && (c.confirmed || bound > c.seed)) {  // every older cluster has passed over it
                     if (!c.confirmed) {
-                        if (seedHit & accepted) {
-                            myDrop = 1;
-                        } else if (decided > c.seed) {
-                            c.confirmed = 1;
-                            myConfirmNow = 1;
-                        }
+                        c.confirmed = 1;
+                        myConfirmNow = 1;
                     }
-                    if (!myDrop) {
-                        // judging costs time even beside the hit, so the next pass looks twice as far as this hit was
-                        if (!c.parked) {
-                            const uint32_t gap = 2u * (myHit - myStart + 1u);
-                            c.chunk = gap < kClusterMinChunk ? kClusterMinChunk : (gap > maxChunk ? maxChunk : gap);
-                        }
-                        if ((sameHit & accepted) || (c.parked && myAssigned)) {  // somebody older has it
-                            c.cursor = myHit + 1u;
-                            c.parked = 0;
-                        } else if (c.confirmed && myHit < decided) {  // every older cluster has passed over it
-                            c.parked = 0;
-                            myAccept = myHit;
-                            c.cursor = myHit + 1u;
-                            wantsRep = c.rep == kClusterOwnRow ? 1u : 0u;
-                        } else {  // an older cluster has not decided that position yet: wait in front of it
-                            c.cursor = myHit;
-                            c.parked = 1;
-                        }
-                    }
-                }
-                const uint32_t cursorNow = __builtin_amdgcn_readlane(c.cursor, k), dropNow = __builtin_amdgcn_readlane(myDrop, k);
-                const uint32_t tookRow = __builtin_amdgcn_readlane(myAccept, k) != kNoCluster ? 1u : 0u;
-                if (dropNow) {
-                    ++dropped;
-                } else {
-                    walkedMin = walkedMin < cursorNow ? walkedMin : cursorNow;
-                    if (tookRow) accepted |= 1u << k;
-                    if (__builtin_amdgcn_readlane(wantsRep, k)) {   // first merge: the lowest free buffer
-                        if (j == k) {
-                            c.rep = (uint32_t)__builtin_ctz(freeReps);
-                            myFirstMerge = 1;
-                        }
-                        freeReps &= freeReps - 1u;
-                    }
+                    takes = true;
+                    myAccept = myHit;
+                    c.cursor = myHit + 1u;
+                    c.parked = 0;
+                } else {  // an older cluster has not decided that position yet: wait in front of it
+                    c.cursor = myHit;
+                    c.parked = 1;
                 }
             }
-            // the unconfirmed clusters that had no hit: dropped when an older cluster took the seed in this pass, confirmed
-            // when every older cluster that stays has its cursor behind the seed
-            if (mine && !walked && !c.confirmed && (seedHit & accepted)) {
-                myDrop = 1;
+            accepted = (uint32_t)__ballot(takes);
+            const uint32_t needs = (uint32_t)__ballot(takes && c.rep == kClusterOwnRow);   // first merges: one free buffer each, in order
+            if (takes && c.rep == kClusterOwnRow) {
+                uint32_t f = freeRepsIn;
+                for (uint32_t n = __popc(needs & ((1u << j) - 1u)); n; --n) f &= f - 1u;
+                c.rep = (uint32_t)__builtin_ctz(f);
+                myFirstMerge = 1;
             }
-            dropped += __popc((uint32_t)__ballot(mine && !walked && myDrop != 0u));
-            uint32_t olderAll = mine && !myDrop ? c.cursor : 0xFFFFFFFFu;
-            for (uint32_t w = 1; w < 32u; w <<= 1) {
-                const uint32_t other = __shfl_up(olderAll, w, 32);
-                if (j >= w) olderAll = olderAll < other ? olderAll : other;
-            }
-            olderAll = __shfl_up(olderAll, 1, 32);
-            if (j == 0) olderAll = 0xFFFFFFFFu;
-            if (mine && !walked && !c.confirmed && !myDrop && olderAll > c.seed) {
+            for (uint32_t n = __popc(needs); n; --n) freeReps &= freeReps - 1u;
+            CLUSTER_STAMP(12);
+            // the unconfirmed clusters: dropped when an older cluster took the seed in this pass, confirmed when every older
+            // cluster that stays has its cursor behind the seed
+            if (mine && !c.confirmed && (seedHit & accepted)) myDrop = 1;
+            dropped = __popc((uint32_t)__ballot(myDrop != 0u));
+            const uint32_t olderAll = olderMinimum(mine && !myDrop ? c.cursor : 0xFFFFFFFFu);
+            if (mine && !c.confirmed && !myDrop && olderAll > c.seed) {
                 c.confirmed = 1;
                 myConfirmNow = 1;
             }
@@ -881,6 +853,13 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
         for (int k = 1; k <= 7; ++k) state->stamps[k] += labT[k] - labT[k - 1];
         state->stamps[8] += labT[8] - labT[3];
         state->stamps[9] += labT[9] - labT[8];
+        if (labT[12]) {
+            state->stamps[10] += labT[10] - labT[8];
+            state->stamps[11] += labT[11] - labT[10];
+            state->stamps[12] += labT[12] - labT[11];
+            state->stamps[13] += labT[9] - labT[12];
+            state->stamps[14] += 1;
+        }
         state->stamps[0] += 1;
 #endif
         state->done = left == 0 && scanPos >= rows ? 1u : 0u;
