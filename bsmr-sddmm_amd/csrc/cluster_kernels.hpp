@@ -42,6 +42,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace bsmr {
 
 constexpr uint32_t kNoCluster = 0xFFFFFFFFu;
@@ -642,52 +644,58 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
     // (a thread's bins are threadIdx.x, threadIdx.x + T, ...: bin % T is the thread's number, so whether its bins take part in
     // the reference's block-wide sums is one bit per thread, not a modulo per bin)
     const bool myBinsCount = (liveWarps >> (threadIdx.x >> 5)) & 1u;
-    if ((numBins + T - 1u) / T <= 8u) {
-        // a thread owns at most eight bins of a representative: the loads of two merges are issued together, all of a thread's
-        // bins at once (one merge after the other, bin after bin, was the longest phase of a small pass)
-        for (uint32_t a0 = 0; a0 < merging; a0 += 2u) {  // uniform
-            uint32_t have[2][8], plus[2][8];
+    // A thread owns few bins of a representative: the loads of several merges are issued together, all of a thread's bins at
+    // once (one merge after the other, bin after bin, was the longest phase of a small pass).
+    auto mergeBatches = [&](auto batchTag, auto binsTag) {
+        constexpr uint32_t NB = decltype(batchTag)::value, NE = decltype(binsTag)::value;
+        for (uint32_t a0 = 0; a0 < merging; a0 += NB) {  // uniform
+            uint32_t have[NB][NE], plus[NB][NE];
 #pragma unroll
-            for (uint32_t b = 0; b < 2u; ++b) {
+            for (uint32_t b = 0; b < NB; ++b) {
                 if (a0 + b >= merging) break;  // uniform
                 const uint32_t j = sHit[a0 + b];
                 const uint32_t* rep = reps + (size_t)sSlot[j].rep * numBins;
                 const ClusterCount* add = table + (size_t)sNew[j] * numBins;
                 const ClusterCount* own = sFirstMerge[j] ? ownRow(j) : nullptr;
 #pragma unroll
-                for (uint32_t k = 0; k < 8u; ++k) {
+                for (uint32_t k = 0; k < NE; ++k) {
                     const uint32_t i = threadIdx.x + k * T;
                     have[b][k] = i < numBins ? (own ? (uint32_t)own[i] : rep[i]) : 0u;
                     plus[b][k] = i < numBins ? (uint32_t)add[i] : 0u;
                 }
             }
 #pragma unroll
-            for (uint32_t b = 0; b < 2u; ++b) {
+            for (uint32_t b = 0; b < NB; ++b) {
                 if (a0 + b >= merging) break;  // uniform
                 const uint32_t j = sHit[a0 + b];
                 uint32_t* rep = reps + (size_t)sSlot[j].rep * numBins;
                 uint32_t sq = 0, tot = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < 8u; ++k) {
+                for (uint32_t k = 0; k < NE; ++k) {
                     const uint32_t i = threadIdx.x + k * T;
                     if (i >= numBins) continue;
                     const uint32_t v = have[b][k] + plus[b][k];
                     rep[i] = v;
-                    if (myBinsCount) {
-                        sq += v * v;
-                        tot += v;
-                    }
+                    sq += v * v;
+                    tot += v;
                 }
+                if (!myBinsCount) sq = tot = 0;
                 for (uint32_t w = lanes >> 1; w >= 1; w >>= 1) {  // `lanes` = 32 in a block's last, half-filled wave
                     sq += __shfl_xor(sq, w, 64);
                     tot += __shfl_xor(tot, w, 64);
                 }
-                if ((threadIdx.x & 63u) == 0) {
+                if ((threadIdx.x & 63u) == 0) {   // (every lane adding by itself - same-address LDS atomics - was slower: 158 -> 196 ms on mycielskian15)
                     atomicAdd(&sSumSq[j], sq);
                     atomicAdd(&sSumTotal[j], tot);
                 }
             }
         }
+    };
+    const uint32_t binsPerThread = (numBins + T - 1u) / T;
+    if (binsPerThread <= 4u) {
+        mergeBatches(std::integral_constant<uint32_t, 4>{}, std::integral_constant<uint32_t, 4>{});
+    } else if (binsPerThread <= 8u) {
+        mergeBatches(std::integral_constant<uint32_t, 2>{}, std::integral_constant<uint32_t, 8>{});
     } else {
         for (uint32_t a = 0; a < merging; ++a) {  // uniform
             const uint32_t j = sHit[a];
