@@ -85,3 +85,20 @@ def test_device_clustering_reproduces_reference_logs(engine, name, pattern, alph
         if alpha == 0.3:
             pipe = engine.Pipeline(csr, alpha=alpha, delta=0.3, block_size=16, device=-1)
             assert np.array_equal(pipe.array("reorderedRows"), perm)
+
+
+def test_clusters_running_ahead_give_the_host_order(engine):
+    """A reddit-like row range (power-law degrees, most rows end in clusters of their own): the passes run ahead of the older
+    clusters' decisions - tentative seeds, parked hits, drops - and the row order and cluster count are the host
+    implementation's all the same."""
+    rows, cols, ro, ci = synth.reddit_shard_like(rows=6000, seed=5)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    bw = csr.calculate_block_size(200 << 30)
+    for alpha in (0.3, 0.6):
+        st, perm, clusters, stats = engine.cluster_rows_device(rows, cols, ro, ci, bw, alpha)
+        assert st == engine.OK
+        pipe = engine.Pipeline(csr, alpha=alpha, delta=0.3, block_size=bw, device=-1)
+        assert np.array_equal(pipe.array("reorderedRows"), perm) and pipe.num_clusters == clusters
+        assert stats["passes_ahead"] > 0, stats
+        print(f"reddit-like 6000 rows alpha={alpha}: {clusters} clusters, {stats['passes']} passes ({stats['passes_ahead']} ahead), "
+              f"{stats['dropped_seeds']} dropped seeds, device {stats['elapsed_ms']:.1f} ms")
