@@ -281,7 +281,9 @@ int bsmr_plan_tune(bsmr_plan *plan, uint32_t K, const float *A_dev, const float 
  * fingerprints launch identical dense work; used to check the device packer against the host packer. */
 int bsmr_plan_format_digest(const bsmr_plan *plan, uint64_t out[13]);
 /* Which dense format a call with inner dimension K uses (any out pointer may be NULL):
- * panels per group, MFMA tiles executed, B columns gathered. */
+ * panels per group, MFMA tiles executed, B columns gathered.  For a plan whose engines were measured (bsmr_plan_tune)
+ * the answer describes the engine of the call that was prepared last - ask right after the bsmr_sddmm call in question
+ * (the untuned rules depend on K alone). */
 int bsmr_plan_dense_choice(const bsmr_plan *plan, uint32_t K, uint32_t *group_size,
                            uint64_t *tiles, uint64_t *union_columns);
 
