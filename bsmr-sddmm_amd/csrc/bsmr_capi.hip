@@ -1838,31 +1838,45 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
             struct Entry {
                 uint32_t col, row, value;
             };
-            std::vector<Entry> entries;
             fBlockOffsets.assign((size_t)P + 1, 0);
             fSparseOffsets.assign((size_t)P + 1, 0);
+            // (panels are independent: sizes first, then every worker sorts its panels into their places - one thread
+            // sorting 4 M entries panel by panel was 33 ms of the cop20k-like plan)
             for (uint32_t q = 0; q < P; ++q) {
-                entries.clear();
-                for (uint32_t i = d->sparse_value_offsets[q]; i < d->sparse_value_offsets[q + 1]; ++i)
-                    entries.push_back({d->sparse_col_indices[i], d->sparse_relative_rows[i], d->sparse_values[i]});
-                for (uint64_t b = d->block_offsets[q]; b < d->block_offsets[q + 1]; ++b)
-                    for (uint32_t r = 0; r < 16; ++r)
-                        for (uint32_t c = 0; c < 16; ++c) {
-                            const uint32_t v = d->block_values[b * 256 + r * 16 + c];
-                            if (v == 0xFFFFFFFFu) continue;
-                            entries.push_back({d->dense_cols[b * 16 + c], r, v});
-                            ++foldedEntries;
-                        }
-                std::sort(entries.begin(), entries.end(), [](const Entry& x, const Entry& y) {
-                    return x.col != y.col ? x.col < y.col : x.row < y.row;
-                });
-                for (const Entry& e : entries) {
-                    fCols.push_back(e.col);
-                    fRows.push_back(e.row);
-                    fValues.push_back(e.value);
-                }
-                fSparseOffsets[q + 1] = (uint32_t)fValues.size();
+                uint32_t stored = 0;
+                for (uint64_t i = (uint64_t)d->block_offsets[q] * 256; i < (uint64_t)d->block_offsets[q + 1] * 256; ++i)
+                    stored += d->block_values[i] != 0xFFFFFFFFu;
+                foldedEntries += stored;
+                fSparseOffsets[q + 1] = fSparseOffsets[q] + (d->sparse_value_offsets[q + 1] - d->sparse_value_offsets[q]) + stored;
             }
+            fCols.resize(fSparseOffsets[P]);
+            fRows.resize(fSparseOffsets[P]);
+            fValues.resize(fSparseOffsets[P]);
+            bsmr::parallelChunks(P, 64, [&](size_t q0, size_t q1, size_t) {
+                std::vector<Entry> entries;
+                for (size_t q = q0; q < q1; ++q) {
+                    entries.clear();
+                    for (uint32_t i = d->sparse_value_offsets[q]; i < d->sparse_value_offsets[q + 1]; ++i)
+                        entries.push_back({d->sparse_col_indices[i], d->sparse_relative_rows[i], d->sparse_values[i]});
+                    for (uint64_t b = d->block_offsets[q]; b < d->block_offsets[q + 1]; ++b)
+                        for (uint32_t r = 0; r < 16; ++r)
+                            for (uint32_t c = 0; c < 16; ++c) {
+                                const uint32_t v = d->block_values[b * 256 + r * 16 + c];
+                                if (v == 0xFFFFFFFFu) continue;
+                                entries.push_back({d->dense_cols[b * 16 + c], r, v});
+                            }
+                    std::sort(entries.begin(), entries.end(), [](const Entry& x, const Entry& y) {
+                        return x.col != y.col ? x.col < y.col : x.row < y.row;
+                    });
+                    size_t at = fSparseOffsets[q];
+                    for (const Entry& e : entries) {
+                        fCols[at] = e.col;
+                        fRows[at] = e.row;
+                        fValues[at] = e.value;
+                        ++at;
+                    }
+                }
+            });
             folded = *d;
             folded.block_offsets = fBlockOffsets.data();
             folded.sparse_value_offsets = fSparseOffsets.data();
