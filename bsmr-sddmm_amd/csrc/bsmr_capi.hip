@@ -2624,8 +2624,82 @@ int timeWholeCalls(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
 }
 }  // namespace
 
+namespace {
+int tunePlan(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode, void* stream, bsmr_tune_report* report);
+inline bsmr_tuned_choice choiceOf(const bsmr_plan::Tuned& t) {
+    bsmr_tuned_choice c{};
+    c.struct_size = (uint32_t)sizeof(bsmr_tuned_choice);
+    c.engine = t.engine; c.group = t.group; c.blocks_per_item = t.blocksPerItem; c.format = t.format;
+    c.b_only = t.bOnly; c.overlap = t.overlap; c.cvt_in_kernel = t.cvt; c.waves = t.waves;
+    return c;
+}
+}  // namespace
+
 int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode, void* stream,
                    bsmr_tune_report* report) {
+    return bsmr_plan_tune_sized(plan, K, A, B, P, mode, stream, report, sizeof(bsmr_tune_report));
+}
+
+int bsmr_plan_tune_sized(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode, void* stream,
+                         bsmr_tune_report* report, size_t report_size) {
+    bsmr_tune_report r{};
+    const int st = tunePlan(plan, K, A, B, P, mode, stream, &r);
+    // (the report only ever grew at its end: a caller built against an older header gets the part it knows)
+    if (st == BSMR_OK && report) memcpy(report, &r, std::min(report_size, sizeof(r)));
+    return st;
+}
+
+int bsmr_plan_get_tuned(const bsmr_plan* plan, uint32_t K, int mode, bsmr_tuned_choice* out) {
+    plan = served(plan);
+    if (!plan || !out || !plan->tunable) return BSMR_ERR_INVALID_ARG;
+    const auto it = plan->tuned.find(((uint64_t)K << 8) | (uint32_t)mode);
+    if (it == plan->tuned.end()) return BSMR_ERR_INVALID_ARG;
+    *out = choiceOf(it->second);
+    return BSMR_OK;
+}
+
+int bsmr_plan_set_tuned(bsmr_plan* plan, uint32_t K, int mode, const bsmr_tuned_choice* choice) {
+    plan = served(plan);
+    if (!plan || !choice || !plan->tunable || choice->struct_size < sizeof(bsmr_tuned_choice)) return BSMR_ERR_INVALID_ARG;
+    if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
+    if (mode != BSMR_COMPUTE_F16 && mode != BSMR_COMPUTE_BF16) return BSMR_ERR_INVALID_ARG;   // (exact fp32 calls have nothing to choose)
+    bsmr_plan::Tuned t;
+    t.engine = choice->engine; t.group = choice->group; t.blocksPerItem = choice->blocks_per_item; t.format = choice->format;
+    t.bOnly = choice->b_only; t.overlap = choice->overlap; t.cvt = choice->cvt_in_kernel; t.waves = choice->waves;
+    const bool engineOk = t.engine == BSMR_ENGINE_STREAM || t.engine == BSMR_ENGINE_TILES || t.engine == BSMR_ENGINE_SHARED ||
+                          t.engine == BSMR_ENGINE_SWEEP || t.engine == BSMR_ENGINE_GEMM;
+    if (!engineOk || t.group < 0 || t.blocksPerItem < 0 || t.format < -1 || t.format > 1 || t.bOnly < -1 || t.bOnly > 1 ||
+        t.overlap < -1 || t.overlap > 1 || t.cvt < -1 || t.cvt > 1 || t.waves < 0)
+        return BSMR_ERR_INVALID_ARG;
+    if (t.format == 1 && !plan->fmt[1].H) return BSMR_ERR_BAD_PLAN;
+    if ((t.engine == BSMR_ENGINE_TILES || t.engine == BSMR_ENGINE_SHARED) && (!tilesServeK(K) || plan->hostDense.entries() == 0)) return BSMR_ERR_BAD_PLAN;
+    if (t.engine == BSMR_ENGINE_SWEEP && (!sweepServesK(K) || plan->hostDense.entries() == 0)) return BSMR_ERR_BAD_PLAN;
+    if (t.engine == BSMR_ENGINE_GEMM && (!gemmServesK(K) || plan->hostDense.entries() == 0)) return BSMR_ERR_BAD_PLAN;
+    if (t.cvt == 1 && !(t.engine == BSMR_ENGINE_SWEEP ? K <= 128 : t.engine == BSMR_ENGINE_GEMM ? gemmFp32ServesK(K) : streamCvtServes(plan->fmt[0], K)))
+        return BSMR_ERR_BAD_PLAN;
+    BSMR_HIP(hipSetDevice(plan->device));
+    const uint64_t key = ((uint64_t)K << 8) | (uint32_t)mode;
+    const auto before = plan->tuned.find(key);
+    const bool had = before != plan->tuned.end();
+    const bsmr_plan::Tuned old = had ? before->second : bsmr_plan::Tuned{};
+    plan->tuned[key] = t;
+    // the engine's device format for this K is built now (a call must not allocate inside a stream capture), and a shape the
+    // plan cannot take is refused here, not silently replaced by the streaming engine later
+    int st = prepareDense(plan, K, mode);
+    if (st == BSMR_OK && t.engine == BSMR_ENGINE_SWEEP && !sweepEngine(plan)) st = BSMR_ERR_BAD_PLAN;
+    if (st == BSMR_OK && t.engine == BSMR_ENGINE_GEMM && !gemmEngine(plan)) st = BSMR_ERR_BAD_PLAN;
+    if (st == BSMR_OK && needsWorkspace(plan, mode, K)) st = reserve(plan, K);
+    if (st != BSMR_OK) {
+        if (had) plan->tuned[key] = old;
+        else plan->tuned.erase(key);
+        (void)prepareDense(plan, K, mode);
+    }
+    return st;
+}
+
+namespace {
+int tunePlan(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode, void* stream,
+             bsmr_tune_report* report) {
     if (!plan) return BSMR_ERR_INVALID_ARG;
     bsmr_tune_report r{};
     if (!plan->retained) {   // no hint: the engines of the plan as it was built
@@ -2705,6 +2779,7 @@ int bsmr_plan_tune(bsmr_plan* plan, uint32_t K, const float* A, const float* B, 
     if (st == BSMR_OK && report) *report = bestReport;
     return st;
 }
+}  // namespace
 
 int bsmr_sddmm_host(bsmr_plan* plan, uint32_t K, const float* A_host, const float* B_host, float* P_host,
                     int mode, int iters, float* ms_per_iter) {
@@ -2768,10 +2843,31 @@ uint32_t liveWarpMask(uint32_t T) {
 
 }  // namespace
 
+namespace {
+int clusterRows(int device, uint32_t rows, uint32_t cols, const uint32_t* row_offsets, const uint32_t* col_indices, uint32_t bin_width,
+                float alpha, uint32_t* reordered_rows, uint32_t* num_reordered, int32_t* num_clusters, bsmr_cluster_stats* stats);
+}
+extern "C" int bsmr_cluster_rows_sized(int device, uint32_t rows, uint32_t cols, const uint32_t* row_offsets,
+                                       const uint32_t* col_indices, uint32_t bin_width, float alpha,
+                                       uint32_t* reordered_rows, uint32_t* num_reordered, int32_t* num_clusters,
+                                       bsmr_cluster_stats* stats, size_t stats_size) {
+    bsmr_cluster_stats full{};
+    const int st = clusterRows(device, rows, cols, row_offsets, col_indices, bin_width, alpha, reordered_rows, num_reordered, num_clusters,
+                               stats ? &full : nullptr);
+    // (the statistics only ever grew at their end: a caller built against an older header gets the part it knows)
+    if (stats) memcpy(stats, &full, std::min(stats_size, sizeof(full)));
+    return st;
+}
 extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const uint32_t* row_offsets,
                                  const uint32_t* col_indices, uint32_t bin_width, float alpha,
                                  uint32_t* reordered_rows, uint32_t* num_reordered, int32_t* num_clusters,
                                  bsmr_cluster_stats* stats) {
+    return bsmr_cluster_rows_sized(device, rows, cols, row_offsets, col_indices, bin_width, alpha, reordered_rows, num_reordered,
+                                   num_clusters, stats, sizeof(bsmr_cluster_stats));
+}
+namespace {
+int clusterRows(int device, uint32_t rows, uint32_t cols, const uint32_t* row_offsets, const uint32_t* col_indices, uint32_t bin_width,
+                float alpha, uint32_t* reordered_rows, uint32_t* num_reordered, int32_t* num_clusters, bsmr_cluster_stats* stats) {
     if (!row_offsets || !reordered_rows || !num_reordered || !num_clusters || bin_width == 0)
         return BSMR_ERR_INVALID_ARG;
     *num_reordered = 0;
@@ -2815,7 +2911,7 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
             !dev.alloc(&dTotals, rows, "hipMalloc(rowTotals)") ||
             !dev.alloc(&dOrder, rows, "hipMalloc(order)") ||
             !dev.alloc(&dCluster, rows, "hipMalloc(cluster)") ||
-            !dev.alloc(&dState, 1, "hipMalloc(state)"))
+            !dev.alloc(&dState, 2, "hipMalloc(state)"))
             return BSMR_ERR_OOM;
         BSMR_HIP(hipMemcpyAsync(dRowOffsets, row_offsets, ((size_t)rows + 1) * 4, hipMemcpyHostToDevice, s));
         if (nnz) BSMR_HIP(hipMemcpyAsync(dCols, col_indices, (size_t)nnz * 4, hipMemcpyHostToDevice, s));
@@ -2915,6 +3011,8 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
             state.freeReps = active >= 32 ? 0xFFFFFFFFu : (1u << active) - 1u;
             BSMR_HIP(hipMemcpyAsync(dOrder, order.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
             BSMR_HIP(hipMemcpyAsync(dCluster, cluster.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
+            // two copies of the state, read and written in turn (clusterPass): launch 0 reads the first
+            BSMR_HIP(hipMemsetAsync(dState, 0, 2 * sizeof(state), s));
             BSMR_HIP(hipMemcpyAsync(dState, &state, sizeof(state), hipMemcpyHostToDevice, s));
             // every pass is a no-op once `done` is set, so passes are enqueued in batches and the
             // flag is read between batches; a pass that does work advances at least one cursor
@@ -2935,17 +3033,21 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
                     if (many)
                         hipLaunchKernelGGL(bsmr::clusterPass<true>, dim3(grid), dim3(T), 0, s, dTable, dSquares, dTotals, dPosInfo,
                                            dEncWords, dOrder, rows, (uint32_t)numBins, alpha, maxChunk, active, live, longRow,
-                                           dReps, dCluster, dState);
+                                           dReps, dCluster, dState, (uint32_t)(enqueued + (uint64_t)i));
                     else
                         hipLaunchKernelGGL(bsmr::clusterPass<false>, dim3(grid), dim3(T), 0, s, dTable, dSquares, dTotals, dPosInfo,
                                            dEncWords, dOrder, rows, (uint32_t)numBins, alpha, maxChunk, active, live, longRow,
-                                           dReps, dCluster, dState);
+                                           dReps, dCluster, dState, (uint32_t)(enqueued + (uint64_t)i));
                 }
                 enqueued += (uint64_t)batch;
                 batch = std::min(256, batch * 4);
                 BSMR_HIP(hipGetLastError());
-                BSMR_HIP(hipMemcpyAsync(&state, dState, sizeof(state), hipMemcpyDeviceToHost, s));
+                // the state the last launch left: the copy launch number `enqueued` would read - or, when the passes ended
+                // earlier in the batch, whichever copy holds the later pass (both then carry the done flag)
+                bsmr::ClusterState both[2];
+                BSMR_HIP(hipMemcpyAsync(both, dState, sizeof(both), hipMemcpyDeviceToHost, s));
                 BSMR_HIP(hipStreamSynchronize(s));
+                state = both[0].done || both[1].done ? (both[0].passes >= both[1].passes ? both[0] : both[1]) : both[enqueued & 1u];
                 const uint64_t work = (uint64_t)state.judged + state.exact, passes = state.passes;
                 if (passes > lastPasses) many = (work - lastWork) > (uint64_t)grid * (passes - lastPasses);
                 if (many && !dEncOffsets && (st = uploadSparseRows()) != BSMR_OK) return st;
@@ -3013,6 +3115,7 @@ extern "C" int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const
         return BSMR_ERR_INVALID_ARG;
     }
 }
+}  // namespace
 
 #include "sharded_capi.hpp"
 #include "colreorder_capi.hpp"

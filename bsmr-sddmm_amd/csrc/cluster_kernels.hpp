@@ -237,7 +237,15 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
                             const uint32_t* __restrict__ encWords,
                             const uint32_t* __restrict__ order, uint32_t rows, uint32_t numBins, float alpha,
                             uint32_t maxChunk, uint32_t maxActive, uint32_t liveWarps, uint32_t longRow, uint32_t* __restrict__ reps,
-                            uint32_t* __restrict__ cluster, ClusterState* __restrict__ state) {
+                            uint32_t* __restrict__ cluster, ClusterState* __restrict__ states, uint32_t ordinal) {
+    // Two copies of the state, used in turn: launch number `ordinal` READS states[ordinal & 1] - nothing but the atomics of
+    // its own participants (arrived, judged, exact, a slot's firstHit) touches that copy while the launch runs - and its
+    // closing workgroup WRITES the next pass's state into the other copy.  A workgroup that has no item in this pass and is
+    // scheduled after the closing workgroup has finished therefore still sees this pass's state and leaves; with one copy it
+    // could read the next pass's totalItems, take itself for a participant of a pass that has not been launched and count
+    // itself into its arrivals.
+    ClusterState* __restrict__ state = states + (ordinal & 1u);
+    ClusterState* __restrict__ next = states + ((ordinal + 1u) & 1u);
     __shared__ float shmA[32], shmB[32];
     __shared__ uint32_t shared[4];
     __shared__ uint32_t sCursor[kClusterMaxActive], sLen[kClusterMaxActive], sStart[kClusterMaxActive + 1];
@@ -843,34 +851,42 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
         if (j + 1 == left || (left == 0 && j == 0)) shared[3] = left ? upTo : 0u;
     }
     __syncthreads();
-    if (threadIdx.x < left) storeSlot(state->slot[threadIdx.x], loadSlot(sSlot[threadIdx.x]));
+    if (threadIdx.x < left) storeSlot(next->slot[threadIdx.x], loadSlot(sSlot[threadIdx.x]));
     if (threadIdx.x == 0) {
-        state->numActive = left;
-        state->nextId = nextId + numNew;
-        state->scanPos = scanPos;
-        state->freeReps = freeReps;
-        state->arrived = 0;
-        state->passes = passesIn + 1;
-        state->ahead = aheadIn + (speculate ? 1u : 0u);
-        state->dropped = droppedIn + dropped;
-        state->tentative = tentative;
-        state->startChunk = startChunk;
-        state->totalItems = shared[3];
+        next->numActive = left;
+        next->nextId = nextId + numNew;
+        next->scanPos = scanPos;
+        next->freeReps = freeReps;
+        next->arrived = 0;
+        next->passes = passesIn + 1;
+        // (every participant added its counts before it arrived, and this workgroup arrived last)
+        next->judged = __hip_atomic_load(&state->judged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        next->exact = __hip_atomic_load(&state->exact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        next->ahead = aheadIn + (speculate ? 1u : 0u);
+        next->dropped = droppedIn + dropped;
+        next->tentative = tentative;
+        next->startChunk = startChunk;
+        next->totalItems = shared[3];
 #ifdef BSMR_LAB_STAMPS
         labT[7] = __builtin_readcyclecounter();
-        for (int k = 1; k <= 7; ++k) state->stamps[k] += labT[k] - labT[k - 1];
-        state->stamps[8] += labT[8] - labT[3];
-        state->stamps[9] += labT[9] - labT[8];
+        for (int k = 0; k < 16; ++k) next->stamps[k] = state->stamps[k];
+        for (int k = 1; k <= 7; ++k) next->stamps[k] += labT[k] - labT[k - 1];
+        next->stamps[8] += labT[8] - labT[3];
+        next->stamps[9] += labT[9] - labT[8];
         if (labT[12]) {
-            state->stamps[10] += labT[10] - labT[8];
-            state->stamps[11] += labT[11] - labT[10];
-            state->stamps[12] += labT[12] - labT[11];
-            state->stamps[13] += labT[9] - labT[12];
-            state->stamps[14] += 1;
+            next->stamps[10] += labT[10] - labT[8];
+            next->stamps[11] += labT[11] - labT[10];
+            next->stamps[12] += labT[12] - labT[11];
+            next->stamps[13] += labT[9] - labT[12];
+            next->stamps[14] += 1;
         }
-        state->stamps[0] += 1;
+        next->stamps[0] += 1;
 #endif
-        state->done = left == 0 && scanPos >= rows ? 1u : 0u;
+        const uint32_t done = left == 0 && scanPos >= rows ? 1u : 0u;
+        next->done = done;
+        // (the launches behind the last pass alternate between the two copies: both say that there is nothing left to do;
+        // the copy with the larger `passes` holds the final state)
+        if (done) state->done = 1u;
     }
 }
 

@@ -1,0 +1,180 @@
+// Device format of the dense part for the output-stationary GEMM engine (round 4), and its host packer.  Pure host C++.
+//
+// What is computed is the dense part of the reference's SDDMM (reference src/sddmmKernel.cu:213-351: per 16 x 16 block
+// a K loop of tensor-core steps, then the masked scatter of the accumulators, :331-348).  The sweep engine (round 3,
+// csrc/sweep_format.hpp) already ignored the blocks' column choice and multiplied natural 16-column blocks of B; it kept
+// the A fragments of a wave for the whole K in registers, so one B fragment fed at most four MFMAs.  This format cuts the
+// product the way a GEMM does: a work item is a MACRO-TILE of C, TM = 16 * PM reordered rows (PM panels, RPHM order) times
+// TN = 16 * NB natural columns; the kernel keeps the whole macro-tile's accumulators in registers over the K loop, each of
+// its WM x WN waves owning an m x n block of 16 x 16 tiles (m = PM / WM, n = NB / WN), so one fragment read of A feeds n
+// MFMAs and one of B feeds m.  The sparse mask is applied once per macro-tile, by construction as in the tiles / sweep
+// engines: a wave drops its accumulators into a private LDS slab (16 tiles at a time: a PASS) and one lane per STORED entry
+// carries its value to P.
+//
+//   panelRows [G * TM]        original row ids, 16 per panel, panels in RPHM order (padding: row 0 of the list)
+//   items     [I]             {row group, first 16-column block, index of its first `lists` word}; macro-tiles WITHOUT a
+//                             dense entry are not listed; order: super-tiles of kGemmSuperRows x kGemmSuperCols macro-tiles
+//                             (what one XCD works on shares its rows of A and columns of B in that XCD's L2)
+//   rowStart  [I][TM]         smallest CSR index among the entries the item holds of that row (0 if none)
+//   lists     [I][W * Q + 1]  wave w, pass q: words[lists[w * Q + q] .. lists[w * Q + q + 1]); Q = m * n / 16 passes;
+//                             every list is padded to a multiple of 4 words with kGemmNoEntry
+//   words     [u32]           one per stored dense entry, lists ordered by (row, column):
+//                             slab slot (12 bits) | row in the wave's rows (7) << 12 | offset (13) << 19
+//                             slab slot = ((tile in pass) * 64 + 16 (r >> 2) + c) * 4 + (r & 3) for row r, column c of a
+//                             16 x 16 tile (the MFMA accumulator layout: lane 16 (r >> 2) + c, register r & 3); tile t of a
+//                             wave = (row tile) * n + (column tile), pass t / 16, tile in pass t % 16
+//                             offset = CSR index - rowStart of its row (< 8191: sorted CSR rows give < TN)
+// An entry is listed iff the RPHM (after the plan's own promotion / folding) has it in a dense block: the dense / sparse
+// assignment of every nnz is unchanged.  Rows need not be sorted, but one row's entries inside one macro-tile must lie
+// within 8191 CSR positions of each other (BSMR_ERR_BAD_PLAN otherwise: the caller keeps the other engines).
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "bsmr_hip.h"
+#include "tile_format.hpp"
+
+namespace bsmr {
+
+constexpr uint32_t kGemmWavesM = 2, kGemmWavesN = 4, kGemmWaves = kGemmWavesM * kGemmWavesN;
+constexpr uint32_t kGemmPassTiles = 16;        // 16 x 16 tiles of a wave per slab pass (16 KiB of fp32 per wave)
+constexpr uint32_t kGemmNoEntry = 0xFFFFFFFFu; // padding word (offset 8191 is never a real offset)
+constexpr uint32_t kGemmMaxOffset = 8191u;
+constexpr uint32_t kGemmSuperRows = 4, kGemmSuperCols = 8;   // macro-tiles per super-tile (one XCD's share of a 256-tile launch)
+constexpr uint32_t kGemmWordSlack = 256;       // words behind the last list that the kernel may read (never use)
+
+struct GemmItem {
+    uint32_t group;        // row group: panels [group * PM, group * PM + PM)
+    uint32_t firstBlock;   // first 16-column block of B
+    uint32_t listBase;     // index of lists[item][0]
+    uint32_t rowStartBase; // index of rowStart[item][0] / TM  (= the item's own index; kept explicit for the kernel)
+};
+
+struct GemmFormatHost {
+    uint32_t PM = 0, NB = 0, numGroups = 0, numStrips = 0, passes = 0;
+    std::vector<uint32_t> panelRows;
+    std::vector<GemmItem> items;
+    std::vector<uint32_t> rowStart;
+    std::vector<uint32_t> lists;
+    std::vector<uint32_t> words;
+    uint64_t numTiles = 0;          // 16 x 16 tiles multiplied: items * PM * NB
+    uint32_t maxListWords = 0;      // longest (wave, pass) list
+    size_t bytes() const {
+        return 4 * (panelRows.size() + rowStart.size() + lists.size() + words.size()) + sizeof(GemmItem) * items.size();
+    }
+};
+
+inline bool gemmShapeOk(uint32_t PM, uint32_t NB) {
+    if (PM % kGemmWavesM || NB % kGemmWavesN) return false;
+    const uint32_t m = PM / kGemmWavesM, n = NB / kGemmWavesN, t = m * n;
+    return m >= 1 && n >= 1 && m <= 8 && t >= kGemmPassTiles && t % kGemmPassTiles == 0 && t <= 32;
+}
+
+// Packs the dense entries for macro-tiles of PM panels x NB 16-column blocks.
+inline int packGemm(const HostDense& hd, uint32_t PM, uint32_t NB, GemmFormatHost& out) {
+    if (!gemmShapeOk(PM, NB)) return BSMR_ERR_INVALID_ARG;
+    const uint32_t P = hd.numPanels, TM = PM * 16;
+    const uint32_t G = (P + PM - 1) / PM, NCB = (hd.N + 15) / 16, S = (NCB + NB - 1) / NB;
+    const uint32_t m = PM / kGemmWavesM, n = NB / kGemmWavesN, Q = m * n / kGemmPassTiles, L = kGemmWaves * Q;
+    out = GemmFormatHost();
+    out.PM = PM; out.NB = NB; out.numGroups = G; out.numStrips = S; out.passes = Q;
+    if (P == 0 || NCB == 0 || hd.entries() == 0) return BSMR_OK;
+    if ((uint64_t)G * S > 0x3FFFFFFFull || hd.entries() > 0xFFFFFFF0ull) return BSMR_ERR_INVALID_ARG;
+    out.panelRows.assign((size_t)G * TM, hd.panelRows.empty() ? 0u : hd.panelRows[0]);
+    std::copy(hd.panelRows.begin(), hd.panelRows.end(), out.panelRows.begin());
+    // 1. which macro-tiles hold entries, entries per (macro-tile, wave, pass) list
+    std::vector<uint32_t> itemOf((size_t)G * S, 0xFFFFFFFFu);   // (g, s) -> item, assigned in super-tile order below
+    std::vector<uint8_t> used((size_t)G * S, 0);
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t g = p / PM;
+        for (uint64_t e = hd.offsets[p]; e < hd.offsets[p + 1]; ++e) used[(size_t)g * S + (hd.col[e] >> 4) / NB] = 1;
+    }
+    const uint32_t SG = (G + kGemmSuperRows - 1) / kGemmSuperRows, SS = (S + kGemmSuperCols - 1) / kGemmSuperCols;
+    for (uint32_t sg = 0; sg < SG; ++sg)
+        for (uint32_t ss = 0; ss < SS; ++ss)
+            for (uint32_t g = sg * kGemmSuperRows; g < std::min(G, (sg + 1) * kGemmSuperRows); ++g)
+                for (uint32_t s = ss * kGemmSuperCols; s < std::min(S, (ss + 1) * kGemmSuperCols); ++s)
+                    if (used[(size_t)g * S + s]) {
+                        itemOf[(size_t)g * S + s] = (uint32_t)out.items.size();
+                        GemmItem it;
+                        it.group = g;
+                        it.firstBlock = s * NB;
+                        it.listBase = (uint32_t)(out.items.size() * (L + 1));
+                        it.rowStartBase = (uint32_t)out.items.size();
+                        out.items.push_back(it);
+                    }
+    const size_t I = out.items.size();
+    out.numTiles = (uint64_t)I * PM * NB;
+    if (I * (size_t)(L + 1) > 0xFFFFFFFFull || I * (size_t)TM > 0xFFFFFFFFull) return BSMR_ERR_INVALID_ARG;
+    out.lists.assign(I * (L + 1), 0);
+    out.rowStart.assign(I * TM, 0xFFFFFFFFu);
+    auto locate = [&](uint32_t p, uint64_t e, size_t& item, uint32_t& list, uint32_t& slot, uint32_t& rowInWave, uint32_t& rowInTile) {
+        const uint32_t g = p / PM, pj = p % PM;                       // panel pj of the group
+        const uint32_t cb = hd.col[e] >> 4, s = cb / NB, bj = cb % NB; // block bj of the macro-tile
+        const uint32_t wm = pj / m, tm = pj % m, wn = bj / n, tn = bj % n;
+        const uint32_t t = tm * n + tn, q = t / kGemmPassTiles, tp = t % kGemmPassTiles;
+        const uint32_t r = hd.row[e], c = hd.col[e] & 15u;
+        item = itemOf[(size_t)g * S + s];
+        list = (wm * kGemmWavesN + wn) * Q + q;
+        slot = (tp * 64 + (r >> 2) * 16 + c) * 4 + (r & 3u);
+        rowInWave = tm * 16 + r;
+        rowInTile = pj * 16 + r;
+    };
+    for (uint32_t p = 0; p < P; ++p)
+        for (uint64_t e = hd.offsets[p]; e < hd.offsets[p + 1]; ++e) {
+            size_t item; uint32_t list, slot, rw, rt;
+            locate(p, e, item, list, slot, rw, rt);
+            ++out.lists[item * (L + 1) + list + 1];
+            uint32_t& rs = out.rowStart[item * TM + rt];
+            rs = std::min(rs, hd.idx[e]);
+        }
+    for (uint32_t& v : out.rowStart)
+        if (v == 0xFFFFFFFFu) v = 0;
+    // 2. prefix sums: the lists of the launch are one run of `words`, each padded to a multiple of 4
+    uint64_t at = 0;
+    for (size_t item = 0; item < I; ++item) {
+        uint32_t* ls = &out.lists[item * (L + 1)];
+        uint64_t run = at;
+        for (uint32_t l = 0; l <= L; ++l) {
+            const uint32_t cnt = ls[l];   // ls[0] is 0, ls[l + 1] held list l's count
+            out.maxListWords = std::max(out.maxListWords, (cnt + 3u) & ~3u);
+            run += (cnt + 3u) & ~3u;
+            if (run > 0xFFFFFFF0ull) return BSMR_ERR_INVALID_ARG;
+            ls[l] = (uint32_t)run;        // start of list l (ls[L]: the end of the item's words)
+        }
+        at = run;
+    }
+    if (at > 0xFFFFFFF0ull) return BSMR_ERR_INVALID_ARG;
+    out.words.assign((size_t)at + kGemmWordSlack, kGemmNoEntry);
+    // 3. the words; HostDense lists a panel's entries by (column, row): collect per list, then order by (row, column)
+    std::vector<uint32_t> fill(out.lists.size());
+    for (size_t item = 0; item < I; ++item)
+        for (uint32_t l = 0; l < L; ++l) fill[item * (L + 1) + l] = out.lists[item * (L + 1) + l];
+    std::vector<uint64_t> keys(hd.entries());   // (row in wave, column, word) packed for the per-list sort
+    for (uint32_t p = 0; p < P; ++p)
+        for (uint64_t e = hd.offsets[p]; e < hd.offsets[p + 1]; ++e) {
+            size_t item; uint32_t list, slot, rw, rt;
+            locate(p, e, item, list, slot, rw, rt);
+            const uint32_t off = hd.idx[e] - out.rowStart[item * TM + rt];
+            if (off >= kGemmMaxOffset) return BSMR_ERR_BAD_PLAN;
+            const uint32_t word = slot | (rw << 12) | (off << 19);
+            uint32_t& pos = fill[item * (L + 1) + list];
+            // key: row in wave (7 bits) | column inside the macro-tile (up to NB * 16 <= 512: 10 bits) | word
+            keys[e] = ((uint64_t)rw << 42) | ((uint64_t)(hd.col[e] - out.items[item].firstBlock * 16u) << 32) | word;
+            out.words[pos++] = (uint32_t)e;   // (the entry's number for now: replaced by the sorted words below)
+        }
+    std::vector<uint64_t> scratch;
+    for (size_t item = 0; item < I; ++item)
+        for (uint32_t l = 0; l < L; ++l) {
+            const uint32_t b = out.lists[item * (L + 1) + l], e = fill[item * (L + 1) + l];
+            scratch.resize(e - b);
+            for (uint32_t i = b; i < e; ++i) scratch[i - b] = keys[out.words[i]];
+            std::sort(scratch.begin(), scratch.end());
+            for (uint32_t i = b; i < e; ++i) out.words[i] = (uint32_t)scratch[i - b];
+        }
+    return BSMR_OK;
+}
+
+}  // namespace bsmr

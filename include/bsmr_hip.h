@@ -143,6 +143,10 @@ int bsmr_device_synchronize(int device);
 #define BSMR_ENGINE_SHARED  2  /* dense part: "tiles" format, B images shared by the 4 waves of a workgroup        */
 #define BSMR_ENGINE_SWEEP   4  /* dense part computed like a GEMM: row groups x strips of B in natural column order,
                                   B streamed once by loader waves, no gather (denseSweep, csrc/sweep_kernels.hpp)  */
+#define BSMR_ENGINE_GEMM    5  /* dense part as an output-stationary masked GEMM (round 4): a workgroup owns a macro-tile of C
+                                  (row panels x natural 16-column blocks), accumulators stay in registers over the K loop,
+                                  A rows and B columns arrive K-slice by K-slice through an LDS double buffer, every wave
+                                  multiplies an m x n block of 16 x 16 tiles (denseGemm, csrc/gemm_kernels.hpp)           */
 #define BSMR_ENGINE_TUNED   3  /* the plan keeps what every engine needs; calls use the streaming engine until
                                   bsmr_plan_tune has timed the three for their (K, mode) and then the fastest          */
 typedef struct bsmr_plan_options {
@@ -274,6 +278,31 @@ typedef struct bsmr_tune_report {
 #define BSMR_VARIANT_ALL_RESIDUE  5   /* the dense part folded into the residue                                   */
 int bsmr_plan_tune(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev, float *P_dev, int mode, void *stream,
                    bsmr_tune_report *report /* may be NULL */);
+/* The same for callers compiled against another revision of this header: bsmr_tune_report only ever grows at its end, and at
+ * most report_size bytes of it are written (bsmr_plan_tune writes sizeof(bsmr_tune_report) of THIS revision: a caller built
+ * against an older header must call bsmr_plan_tune_sized with its own sizeof, INTEGRATION.md "ABI revisions"). */
+int bsmr_plan_tune_sized(bsmr_plan *plan, uint32_t K, const float *A_dev, const float *B_dev, float *P_dev, int mode, void *stream,
+                         bsmr_tune_report *report /* may be NULL */, size_t report_size);
+
+/* What a tuned plan keeps per (K, mode), as plain numbers: bsmr_plan_get_tuned reads the choice bsmr_plan_tune made
+ * (BSMR_ERR_INVALID_ARG when that (K, mode) was never tuned), bsmr_plan_set_tuned installs one WITHOUT timing anything -
+ * a second process (a profiler pass, a later run on the same matrix) replays the measured choice of the first and launches
+ * exactly its kernels.  The choice is validated (the engine must serve this K and its device format must be buildable:
+ * BSMR_ERR_INVALID_ARG / BSMR_ERR_BAD_PLAN otherwise, the plan unchanged).  Plans created with k_hint keep their variant:
+ * these two calls address the engines of the plan that serves the calls.  The reference has no counterpart. */
+typedef struct bsmr_tuned_choice {
+    uint32_t struct_size;     /* sizeof(bsmr_tuned_choice) of the caller */
+    int32_t  engine;          /* BSMR_ENGINE_STREAM / _TILES / _SHARED / _SWEEP / _GEMM */
+    int32_t  group;           /* tiles / shared: panels per group; sweep: panels per consumer wave; gemm: macro-tile rows / 16; 0 = the engine's rule */
+    int32_t  blocks_per_item; /* shared: blocks per work item; sweep: blocks per strip; gemm: macro-tile columns / 16; 0 = the engine's rule */
+    int32_t  format;          /* streaming engine: 0 = one panel per group, 1 = the grouped format, -1 = the rule */
+    int32_t  b_only;          /* all-sparse plans: 1 = B converted alone, 0 = fp32 residue, -1 = the rule */
+    int32_t  overlap;         /* hybrid plans: 1 = residue on the side stream, 0 = one stream, -1 = as the plan was built */
+    int32_t  cvt_in_kernel;   /* 1 = fp32 operands rounded inside the dense kernel, 0 = conversion pass, -1 = the rule */
+    int32_t  waves;           /* sweep: consumer waves; 0 = the rule */
+} bsmr_tuned_choice;
+int bsmr_plan_get_tuned(const bsmr_plan *plan, uint32_t K, int mode, bsmr_tuned_choice *out);
+int bsmr_plan_set_tuned(bsmr_plan *plan, uint32_t K, int mode, const bsmr_tuned_choice *choice);
 
 /* Fingerprint of the plan's first dense format as it lies in device memory: FNV-1a of groupRows, rowBase, winLen,
  * winMask, blockCols, the destination tiles (8-bit or mask form), blockMask and the work items, then the numbers of
@@ -309,6 +338,12 @@ int bsmr_cluster_rows(int device, uint32_t rows, uint32_t cols, const uint32_t *
                       const uint32_t *col_indices, uint32_t bin_width, float alpha,
                       uint32_t *reordered_rows, uint32_t *num_reordered, int32_t *num_clusters,
                       bsmr_cluster_stats *stats);
+/* ... for callers compiled against another revision of this header (bsmr_cluster_stats only grows at its end): at most
+ * stats_size bytes of it are written. */
+int bsmr_cluster_rows_sized(int device, uint32_t rows, uint32_t cols, const uint32_t *row_offsets,
+                            const uint32_t *col_indices, uint32_t bin_width, float alpha,
+                            uint32_t *reordered_rows, uint32_t *num_reordered, int32_t *num_clusters,
+                            bsmr_cluster_stats *stats, size_t stats_size);
 
 /* Column reordering, dense / sparse split and the RPHM index arrays of the BSMR pipeline on the device:
  * colReordering_cpu (src/colReordering.cu:274-404; the reference's own GPU version, :146-241, is unfinished) followed by
