@@ -13,10 +13,12 @@
 //
 //   panelRows [G * TM]        original row ids, 16 per panel, panels in RPHM order (padding: row 0 of the list)
 //   items     [I]             {row group, first 16-column block, index of its first `lists` word}; macro-tiles WITHOUT a
-//                             dense entry are not listed; order: super-tiles of kGemmSuperRows x kGemmSuperCols macro-tiles
-//                             (what one XCD works on shares its rows of A and columns of B in that XCD's L2)
+//                             dense entry are not listed.  Order (gemmItemPlace): column slabs of kGemmSlabStrips strips,
+//                             inside a slab row group by row group - a launch's eighth (what one XCD works on) is a few row
+//                             groups x one slab and shares its rows of A and columns of B in that XCD's L2.  When every
+//                             macro-tile is listed (fullGrid) the kernel computes an item's place instead of loading it.
 //   rowStart  [I][TM]         smallest CSR index among the entries the item holds of that row (0 if none)
-//   lists     [I][W * Q + 1]  wave w, pass q: words[lists[w * Q + q] .. lists[w * Q + q + 1]); Q = m * n / 16 passes;
+//   lists     [I][W * Q + 1]  wave w, pass q: words[lists[w * Q + q] .. lists[w * Q + q + 1]); Q = ceil(m n / 16) passes;
 //                             every list is padded to a multiple of 4 words with kGemmNoEntry
 //   words     [u32]           one per stored dense entry, lists ordered by (row, column):
 //                             slab slot (12 bits) | row in the wave's rows (7) << 12 | offset (13) << 19
@@ -42,18 +44,31 @@ constexpr uint32_t kGemmWavesM = 2, kGemmWavesN = 4, kGemmWaves = kGemmWavesM * 
 constexpr uint32_t kGemmPassTiles = 16;        // 16 x 16 tiles of a wave per slab pass (16 KiB of fp32 per wave)
 constexpr uint32_t kGemmNoEntry = 0xFFFFFFFFu; // padding word (offset 8191 is never a real offset)
 constexpr uint32_t kGemmMaxOffset = 8191u;
-constexpr uint32_t kGemmSuperRows = 4, kGemmSuperCols = 8;   // macro-tiles per super-tile (one XCD's share of a 256-tile launch)
-constexpr uint32_t kGemmWordSlack = 256;       // words behind the last list that the kernel may read (never use)
+constexpr uint32_t kGemmSlabStrips = 8;        // column strips per slab of the item order
+constexpr uint32_t kGemmWordSlack = 1024;      // words behind the last list that the kernel may read (never use)
 
 struct GemmItem {
     uint32_t group;        // row group: panels [group * PM, group * PM + PM)
     uint32_t firstBlock;   // first 16-column block of B
     uint32_t listBase;     // index of lists[item][0]
-    uint32_t rowStartBase; // index of rowStart[item][0] / TM  (= the item's own index; kept explicit for the kernel)
+    uint32_t pad;
 };
+
+// place of item i in a full grid of G row groups x S column strips: slabs of kGemmSlabStrips strips (the last one narrower),
+// inside a slab row-major
+__host__ __device__ inline void gemmItemPlace(uint32_t i, uint32_t G, uint32_t S, uint32_t& group, uint32_t& strip) {
+    const uint32_t slabs = (S + kGemmSlabStrips - 1u) / kGemmSlabStrips;
+    uint32_t slab = i / (kGemmSlabStrips * G);
+    if (slab >= slabs) slab = slabs - 1u;
+    const uint32_t width = slab + 1u < slabs ? kGemmSlabStrips : S - kGemmSlabStrips * (slabs - 1u);
+    const uint32_t rem = i - slab * kGemmSlabStrips * G;
+    group = rem / width;
+    strip = slab * kGemmSlabStrips + rem % width;
+}
 
 struct GemmFormatHost {
     uint32_t PM = 0, NB = 0, numGroups = 0, numStrips = 0, passes = 0;
+    bool fullGrid = false;          // every macro-tile of the G x S grid is an item
     std::vector<uint32_t> panelRows;
     std::vector<GemmItem> items;
     std::vector<uint32_t> rowStart;
@@ -66,10 +81,9 @@ struct GemmFormatHost {
     }
 };
 
+// m = PM / 2 row tiles x n = NB / 4 column tiles per wave: 4 m n accumulator registers (at most 160 of the 256)
 inline bool gemmShapeOk(uint32_t PM, uint32_t NB) {
-    if (PM % kGemmWavesM || NB % kGemmWavesN) return false;
-    const uint32_t m = PM / kGemmWavesM, n = NB / kGemmWavesN, t = m * n;
-    return m >= 1 && n >= 1 && m <= 8 && t >= kGemmPassTiles && t % kGemmPassTiles == 0 && t <= 32;
+    return (PM == 8 || PM == 16) && (NB == 8 || NB == 12 || NB == 16 || NB == 20);
 }
 
 // Packs the dense entries for macro-tiles of PM panels x NB 16-column blocks.
@@ -77,7 +91,7 @@ inline int packGemm(const HostDense& hd, uint32_t PM, uint32_t NB, GemmFormatHos
     if (!gemmShapeOk(PM, NB)) return BSMR_ERR_INVALID_ARG;
     const uint32_t P = hd.numPanels, TM = PM * 16;
     const uint32_t G = (P + PM - 1) / PM, NCB = (hd.N + 15) / 16, S = (NCB + NB - 1) / NB;
-    const uint32_t m = PM / kGemmWavesM, n = NB / kGemmWavesN, Q = m * n / kGemmPassTiles, L = kGemmWaves * Q;
+    const uint32_t m = PM / kGemmWavesM, n = NB / kGemmWavesN, Q = (m * n + kGemmPassTiles - 1) / kGemmPassTiles, L = kGemmWaves * Q;
     out = GemmFormatHost();
     out.PM = PM; out.NB = NB; out.numGroups = G; out.numStrips = S; out.passes = Q;
     if (P == 0 || NCB == 0 || hd.entries() == 0) return BSMR_OK;
@@ -91,20 +105,19 @@ inline int packGemm(const HostDense& hd, uint32_t PM, uint32_t NB, GemmFormatHos
         const uint32_t g = p / PM;
         for (uint64_t e = hd.offsets[p]; e < hd.offsets[p + 1]; ++e) used[(size_t)g * S + (hd.col[e] >> 4) / NB] = 1;
     }
-    const uint32_t SG = (G + kGemmSuperRows - 1) / kGemmSuperRows, SS = (S + kGemmSuperCols - 1) / kGemmSuperCols;
-    for (uint32_t sg = 0; sg < SG; ++sg)
-        for (uint32_t ss = 0; ss < SS; ++ss)
-            for (uint32_t g = sg * kGemmSuperRows; g < std::min(G, (sg + 1) * kGemmSuperRows); ++g)
-                for (uint32_t s = ss * kGemmSuperCols; s < std::min(S, (ss + 1) * kGemmSuperCols); ++s)
-                    if (used[(size_t)g * S + s]) {
-                        itemOf[(size_t)g * S + s] = (uint32_t)out.items.size();
-                        GemmItem it;
-                        it.group = g;
-                        it.firstBlock = s * NB;
-                        it.listBase = (uint32_t)(out.items.size() * (L + 1));
-                        it.rowStartBase = (uint32_t)out.items.size();
-                        out.items.push_back(it);
-                    }
+    for (uint32_t i = 0; i < G * S; ++i) {   // the order of gemmItemPlace, macro-tiles without entries left out
+        uint32_t g, st;
+        gemmItemPlace(i, G, S, g, st);
+        if (!used[(size_t)g * S + st]) continue;
+        itemOf[(size_t)g * S + st] = (uint32_t)out.items.size();
+        GemmItem it;
+        it.group = g;
+        it.firstBlock = st * NB;
+        it.listBase = (uint32_t)(out.items.size() * (L + 1));
+        it.pad = 0;
+        out.items.push_back(it);
+    }
+    out.fullGrid = out.items.size() == (size_t)G * S;
     const size_t I = out.items.size();
     out.numTiles = (uint64_t)I * PM * NB;
     if (I * (size_t)(L + 1) > 0xFFFFFFFFull || I * (size_t)TM > 0xFFFFFFFFull) return BSMR_ERR_INVALID_ARG;

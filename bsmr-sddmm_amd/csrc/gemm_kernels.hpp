@@ -15,15 +15,21 @@
 //     (piece ^ ((row >> 1) & 7)), the image itself is lane-linear as LDS-DMA requires; the fragment reads apply the same XOR
 //     and are bank-conflict free (a ds_read_b128 is served in groups of 16 lanes: rows 0-3, 12-15 at k-group g and rows
 //     4-11 at g + 1 land on 16 different 16-byte slots of the 256-byte bank row).
-//   * Per slice a wave reads m + n fragments per 32-k step (ds_read_b128) and issues m n MFMAs (v_mfma_f32_16x16x32): one
-//     fragment of A feeds n MFMAs, one of B feeds m (the sweep engine of round 3: at most 4 and 1).  The slice is worked off
-//     in four quadrants of the wave's block (rows top / bottom x columns left / right), so that 32 + 16 registers hold the
-//     fragments; the loads of slice t + 1 are issued before the quadrants of slice t and waited for (counted, this wave's
-//     own) behind them; ONE workgroup barrier per slice publishes the landed stage and frees the other one.
+//   * Per slice and 32-k step a wave reads m + n fragments (ds_read_b128) and issues m n MFMAs (v_mfma_f32_16x16x32): one
+//     fragment of A feeds n MFMAs, one of B feeds m (the sweep engine of round 3: at most 4 and 1).  The loads of slice
+//     t + 1 are issued at the top of slice t and waited for (this wave's own) behind its MFMAs; ONE workgroup barrier per
+//     slice publishes the landed stage and frees the other one.  (What hipcc makes of it, and it is what one wants: the
+//     fragment reads of slice t stay in front of the barrier, its MFMAs move behind it - register-only instructions are not
+//     ordered by the barrier - and run beside the DMA issue and the fragment reads of slice t + 1.)
 //   * Epilogue = the sparse mask: the stages are dead, every wave takes 16 KiB of them as its private slab.  Per pass of 16
 //     tiles: accumulators -> slab (ds_write_b128 per tile), then one lane per STORED entry: entry word -> slab value and the
 //     row's first index (a table of the macro-tile in LDS) -> one store.  The words of a (wave, pass) list are contiguous
-//     and ordered by (row, column): 64 lanes read 256 contiguous bytes and write runs of P.
+//     and ordered by (row, column): 64 lanes read 256 contiguous bytes and write runs of P.  Entry words are read once per
+//     launch, i.e. from HBM: the first eight batches of a pass are requested one phase ahead (pass 0's in front of the last
+//     slice's MFMAs).
+// Measured (tools/probes/gemm_probe.hip, MI355X): 4096^2 Bernoulli(0.1), K = 512, bf16: the K loop runs at 1.5 us per slice
+// = 1.4 PFLOP/s executed, the rate of the guide's 256^2 8-phase GEMM template on random data; what is left is the fixed
+// part (launch, first stage, epilogue).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -43,6 +49,7 @@ constexpr uint32_t gemmRingBytes(int PM, int NB) {
     return 2u * gemmStageBytes(PM, NB) > kGemmWaves * kGemmSlabBytes ? 2u * gemmStageBytes(PM, NB) : kGemmWaves * kGemmSlabBytes;
 }
 constexpr size_t gemmLdsBytes(int PM, int NB) { return gemmRingBytes(PM, NB) + (size_t)PM * 16u * 4u; }
+constexpr uint32_t kGemmWordChunk = 8;                             // batches of 64 entry words requested together
 
 #if defined(BSMR_GEMM_LAB)
 #define GEMM_LAB_ARG , uint32_t labSkip   /* bit 0 MFMAs, 1 fragment reads, 2 DMAs, 3 slab writes, 4 entry loads, 5 stores */
@@ -70,25 +77,25 @@ __device__ __forceinline__ void gemmStage(const uint16_t* A, uint32_t aBytes, co
     const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A), 0, aBytes, 0x00020000);
     const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(B), 0, bBytes, 0x00020000);
 #pragma unroll
-    for (uint32_t j = 0; j < ADMAS; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(stage + (wave * ADMAS + j) * 1024u), 16, voffA[j],
-                                                 kOff, 0, 0);
-#pragma unroll
     for (uint32_t j = 0; j < BDMAS; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (__attribute__((address_space(3))) void*)(stage + bAt + (wave * BDMAS + j) * 1024u), 16,
                                                  voffB[j], kOff, 0, 0);
+#pragma unroll
+    for (uint32_t j = 0; j < ADMAS; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(stage + (wave * ADMAS + j) * 1024u), 16, voffA[j],
+                                                 kOff, 0, 0);
 }
 
+// grid: numItems x batches.  gridG / gridS: row groups / column strips of the format; fullGrid != 0: every macro-tile is an
+// item and item i's place follows from i alone (gemmItemPlace), so nothing waits for the item record.
 template <int KT, int PM, int NB, int MODE>
 __global__ void __launch_bounds__(kGemmWaves * kWave, 2)
 denseGemm(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, uint32_t aBytes, uint32_t bBytes,
           const uint32_t* __restrict__ panelRows, const GemmItem* __restrict__ items, const uint32_t* __restrict__ rowStart,
           const uint32_t* __restrict__ lists, const uint32_t* __restrict__ words, float* __restrict__ P, uint32_t N,
-          Batch batch GEMM_LAB_ARG) {
+          uint32_t gridG, uint32_t gridS, uint32_t fullGrid, Batch batch GEMM_LAB_ARG) {
     constexpr uint32_t K = kGemmBK * KT, TM = PM * 16u, TN = NB * 16u;
-    constexpr uint32_t m = PM / kGemmWavesM, n = NB / kGemmWavesN, Q = m * n / kGemmPassTiles;
-    constexpr uint32_t MH = m / 2 ? m / 2 : 1, NH = n / 2 ? n / 2 : 1;          // tiles per quadrant side
-    constexpr uint32_t QM = m / MH, QN = n / NH;                                // quadrants per side (1 or 2)
+    constexpr uint32_t m = PM / kGemmWavesM, n = NB / kGemmWavesN, Q = (m * n + kGemmPassTiles - 1u) / kGemmPassTiles, L = kGemmWaves * Q;
     constexpr uint32_t ADMAS = PM / 4u, BDMAS = NB / 4u;                        // LDS-DMA instructions per wave and slice
     static_assert(PM % 4 == 0 && NB % 4 == 0, "a stage is filled in whole 1-KiB pieces per wave");
     constexpr uint32_t stageBytes = gemmStageBytes(PM, NB), bAt = TM * kGemmRowBytes;
@@ -96,7 +103,17 @@ denseGemm(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, ui
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t itemId = xcdContiguous(blockIdx.x, gridDim.x);
-    const GemmItem item = items[itemId];
+    uint32_t group, firstBlock, listBase;
+    if (fullGrid) {
+        gemmItemPlace(itemId, gridG, gridS, group, firstBlock);
+        firstBlock *= (uint32_t)NB;
+        listBase = itemId * (L + 1u);
+    } else {
+        const GemmItem item = items[itemId];
+        group = item.group;
+        firstBlock = item.firstBlock;
+        listBase = item.listBase;
+    }
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t wm = wave / kGemmWavesN, wn = wave % kGemmWavesN;
     const uint32_t r = lane & 15u, g = lane >> 4;
@@ -105,24 +122,29 @@ denseGemm(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, ui
     const uint16_t* Bb = B16 + (size_t)blockIdx.y * batch.strideB;
     P += (size_t)blockIdx.y * batch.strideP;
 
-    // the macro-tile's table of first indices, one row per thread
-    if (threadIdx.x < TM) reinterpret_cast<uint32_t*>(lds + rowTableAt)[threadIdx.x] = rowStart[(size_t)item.rowStartBase * TM + threadIdx.x];
-
     // my pieces of a stage: DMA instruction i = wave * DMAS + j moves rows 8 i .. 8 i + 7, lane l the 16-byte slot l & 7 of
     // row 8 i + (l >> 3); the piece that belongs in that slot is slot ^ ((row >> 1) & 7)
     uint32_t voffA[ADMAS], voffB[BDMAS];
 #pragma unroll
     for (uint32_t j = 0; j < ADMAS; ++j) {
         const uint32_t row = 8u * (wave * ADMAS + j) + (lane >> 3);
-        const uint32_t id = panelRows[(size_t)item.group * TM + row];
+        const uint32_t id = panelRows[(size_t)group * TM + row];
         voffA[j] = id * (K * 2u) + (((lane & 7u) ^ ((row >> 1) & 7u)) << 4);
     }
 #pragma unroll
     for (uint32_t j = 0; j < BDMAS; ++j) {
         const uint32_t col = 8u * (wave * BDMAS + j) + (lane >> 3);
-        const uint32_t id = min(item.firstBlock * 16u + col, N - 1u);            // the last block of B may be ragged
+        const uint32_t id = min(firstBlock * 16u + col, N - 1u);                 // the last block of B may be ragged
         voffB[j] = id * (K * 2u) + (((lane & 7u) ^ ((col >> 1) & 7u)) << 4);
     }
+    if (!GEMM_LAB_SKIP(2)) gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds, bAt, wave, voffA, voffB, 0u);
+    // the macro-tile's table of first indices, one row per thread
+    if (threadIdx.x < TM) reinterpret_cast<uint32_t*>(lds + rowTableAt)[threadIdx.x] = rowStart[(size_t)itemId * TM + threadIdx.x];
+    // entry lists of this wave: words[myList[q] .. myList[q + 1]) is pass q's
+    uint32_t myList[Q + 1];
+#pragma unroll
+    for (uint32_t q = 0; q <= Q; ++q) myList[q] = lists[listBase + wave * Q + q];
+
     // fragment addresses: row / column r of a tile, k-group g; piece 4 s + g of the 128-byte row sits at slot (4 s + g) ^ (r >> 1)
     const uint32_t fragOff = r * kGemmRowBytes + ((g ^ (r >> 1)) << 4);        // s = 0; s = 1 is this ^ 64
     const uint32_t aRead = wm * (TM / 2u) * kGemmRowBytes + fragOff;
@@ -134,7 +156,13 @@ denseGemm(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, ui
 #pragma unroll
         for (uint32_t j = 0; j < n; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (!GEMM_LAB_SKIP(2)) gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds, bAt, wave, voffA, voffB, 0u);
+    // entry words, kGemmWordChunk batches of 64 at a time (reads past a list stay inside `words`: its slack)
+    auto loadWords = [&](uint32_t e0, uint32_t (&w)[kGemmWordChunk]) {
+#pragma unroll
+        for (uint32_t u = 0; u < kGemmWordChunk; ++u) w[u] = GEMM_LAB_SKIP(4) ? kGemmNoEntry : words[e0 + u * kWave + lane];
+    };
+    uint32_t wNext[kGemmWordChunk];
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -142,48 +170,31 @@ denseGemm(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, ui
     for (uint32_t t = 0; t < (uint32_t)KT; ++t) {
         if (t + 1u < (uint32_t)KT && !GEMM_LAB_SKIP(2))   // slice t + 1 -> the other stage
             gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds + ((t + 1u) & 1u) * stageBytes, bAt, wave, voffA, voffB, (t + 1u) * kGemmRowBytes);
+        if (t + 1u == (uint32_t)KT) loadWords(myList[0], wNext);   // pass 0's first words: an HBM round trip, hidden behind the last slice
         const uint8_t* base = lds + (t & 1u) * stageBytes;
-        // quadrants in the order (top, left) (top, right) (bottom, right) (bottom, left): only one side's fragments change
-        // between two quadrants, the other side's stay in registers
-        u32x4 af[MH][2], bf[NH][2];
 #pragma unroll
-        for (uint32_t qi = 0; qi < QM * QN; ++qi) {
-            const uint32_t qm = QN == 1 ? qi : qi / 2u, qn = QN == 1 ? 0u : (qi == 1u || qi == 2u ? 1u : 0u);
-            const bool newA = qi == 0u || (QN == 1 ? true : qi == 2u), newB = qi != 2u || QN == 1;
+        for (uint32_t s = 0; s < 2; ++s) {
+            u32x4 bf[n];
             if (!GEMM_LAB_SKIP(1)) {
-                if (newB) {
 #pragma unroll
-                    for (uint32_t j = 0; j < NH; ++j)
-#pragma unroll
-                        for (uint32_t s = 0; s < 2; ++s)
-                            bf[j][s] = *reinterpret_cast<const u32x4*>(base + ((bRead + (qn * NH + j) * 16u * kGemmRowBytes) ^ (s << 6)));
-                }
-                if (newA) {
-#pragma unroll
-                    for (uint32_t i = 0; i < MH; ++i)
-#pragma unroll
-                        for (uint32_t s = 0; s < 2; ++s)
-                            af[i][s] = *reinterpret_cast<const u32x4*>(base + ((aRead + (qm * MH + i) * 16u * kGemmRowBytes) ^ (s << 6)));
-                }
+                for (uint32_t j = 0; j < n; ++j) bf[j] = *reinterpret_cast<const u32x4*>(base + ((bRead + j * 16u * kGemmRowBytes) ^ (s << 6)));
             } else {
 #pragma unroll
-                for (uint32_t j = 0; j < NH; ++j) bf[j][0] = bf[j][1] = u32x4{lane, t, j, 1u};
-#pragma unroll
-                for (uint32_t i = 0; i < MH; ++i) af[i][0] = af[i][1] = u32x4{lane, t, i, 2u};
+                for (uint32_t j = 0; j < n; ++j) bf[j] = u32x4{lane, t, j, s};
             }
-            if (!GEMM_LAB_SKIP(0)) {
 #pragma unroll
-                for (uint32_t s = 0; s < 2; ++s)
+            for (uint32_t i = 0; i < m; ++i) {
+                u32x4 af;
+                if (!GEMM_LAB_SKIP(1)) af = *reinterpret_cast<const u32x4*>(base + ((aRead + i * 16u * kGemmRowBytes) ^ (s << 6)));
+                else af = u32x4{lane, t, i, s + 2u};
+                if (!GEMM_LAB_SKIP(0)) {
 #pragma unroll
-                    for (uint32_t i = 0; i < MH; ++i)
+                    for (uint32_t j = 0; j < n; ++j) acc[i][j] = mfma16<MODE>(af, bf[j], acc[i][j]);
+                } else {
+                    gemmKeep(af);
 #pragma unroll
-                        for (uint32_t j = 0; j < NH; ++j)
-                            acc[qm * MH + i][qn * NH + j] = mfma16<MODE>(af[i][s], bf[j][s], acc[qm * MH + i][qn * NH + j]);
-            } else {
-#pragma unroll
-                for (uint32_t i = 0; i < MH; ++i)
-#pragma unroll
-                    for (uint32_t j = 0; j < NH; ++j) { gemmKeep(af[i][0]); gemmKeep(af[i][1]); gemmKeep(bf[j][0]); gemmKeep(bf[j][1]); }
+                    for (uint32_t j = 0; j < n; ++j) gemmKeep(bf[j]);
+                }
             }
         }
         // slice t + 1 has landed (this wave's pieces), everybody has read slice t: the stages change roles
@@ -194,23 +205,24 @@ denseGemm(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, ui
     // ---- the sparse mask: slab passes over the wave's tiles
     float* slab = reinterpret_cast<float*>(lds) + wave * (kGemmPassTiles * 256u);
     const uint32_t* rowTable = reinterpret_cast<const uint32_t*>(lds + rowTableAt) + wm * (TM / 2u);
-    const uint32_t* myLists = lists + item.listBase + wave * Q;
 #pragma unroll
     for (uint32_t q = 0; q < Q; ++q) {
         if (!GEMM_LAB_SKIP(3)) {
 #pragma unroll
             for (uint32_t tp = 0; tp < kGemmPassTiles; ++tp) {
                 const uint32_t tIdx = q * kGemmPassTiles + tp;
-                *reinterpret_cast<f32x4*>(slab + (tp * 64u + lane) * 4u) = acc[tIdx / n][tIdx % n];
+                if (tIdx < m * n) *reinterpret_cast<f32x4*>(slab + (tp * 64u + lane) * 4u) = acc[tIdx / n][tIdx % n];
             }
         }
-        const uint32_t first = myLists[q], last = myLists[q + 1u];
-        for (uint32_t e = first; e < last; e += 4u * kWave) {
-            uint32_t w[4];
+        const uint32_t first = myList[q], last = myList[q + 1u];
+        uint32_t w[kGemmWordChunk];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) w[u] = GEMM_LAB_SKIP(4) ? kGemmNoEntry : words[e + u * kWave + lane];   // (reads past the list stay inside `words`: its slack)
+        for (uint32_t u = 0; u < kGemmWordChunk; ++u) w[u] = wNext[u];
+        if (q + 1u < Q) loadWords(last, wNext);                     // the next pass's first words (lists follow each other)
+        for (uint32_t e = first; e < last; e += kGemmWordChunk * kWave) {
+            if (e != first) loadWords(e, w);                         // (a list of more than 512 words: rare)
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kGemmWordChunk; ++u) {
                 if (e + u * kWave + lane < last && w[u] != kGemmNoEntry) {
                     const float val = slab[w[u] & 4095u];
                     const uint32_t dst = rowTable[(w[u] >> 12) & 127u] + (w[u] >> 19);

@@ -256,6 +256,9 @@ int bsmr_sharded_sddmm_host(bsmr_sharded* s, uint32_t K, const float* A_host, co
                 !hipOk(hipMalloc(reinterpret_cast<void**>(&s->B[i]), std::max<size_t>((size_t)s->N * K * 4, 16)), "hipMalloc(B replica)") ||
                 !hipOk(hipMalloc(reinterpret_cast<void**>(&s->P[i]), std::max<size_t>(part * 4, 16)), "hipMalloc(P shard)"))
                 return BSMR_ERR_OOM;
+            // (every entry of P is written by exactly one shard's SDDMM or arrives with the gather: a byte pattern that reads
+            // as NaN makes an entry that nobody wrote visible to the caller)
+            BSMR_HIP(hipMemsetAsync(s->P[i], 0xFF, std::max<size_t>(part * 4, 16), s->streams[i]));
             int st = s->plans[i] ? bsmr_plan_reserve(s->plans[i], K) : BSMR_OK;
             if (st != BSMR_OK) return st;
         }

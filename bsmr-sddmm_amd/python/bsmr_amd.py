@@ -54,7 +54,14 @@ class TuneReport(C.Structure):
                 ("chosen_overlap", C.c_int32), ("one_stream_us", C.c_float), ("two_streams_us", C.c_float),
                 ("chosen_cvt_in_kernel", C.c_int32), ("convert_pass_us", C.c_float), ("fp32_dense_us", C.c_float),
                 ("sweep_us", C.c_float), ("lowp_call_us", C.c_float), ("sweep_fp32_call_us", C.c_float),
-                ("chosen_sweep_fp32", C.c_int32), ("chosen_variant", C.c_int32), ("variant_us", C.c_float * 6)]
+                ("chosen_sweep_fp32", C.c_int32), ("chosen_variant", C.c_int32), ("variant_us", C.c_float * 6),
+                ("gemm_us", C.c_float)]
+
+
+class TunedChoice(C.Structure):
+    """bsmr_tuned_choice: what a tuned plan keeps per (K, mode) (bsmr_plan_get_tuned / bsmr_plan_set_tuned)"""
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in (
+        "engine", "group", "blocks_per_item", "format", "b_only", "overlap", "cvt_in_kernel", "waves")]
 
 
 class PlanBuildMs(C.Structure):
@@ -81,11 +88,11 @@ class PlanOptions(C.Structure):
         "column_order", "dense_stream", "dense_batch", "tile_group", "tile_blocks_per_item", "tile_depth",
         "sparse_entries_per_item", "sparse_lowp", "sparse_lpe", "free_residue", "convert_in_kernel", "convert_sliced",
         "b_only", "b_only_work_m", "overlap_streams", "mask_tiles", "pack_on_device", "sweep_panels", "sweep_strip_blocks",
-        "sweep_fp32", "sweep_waves", "sweep_per_cu", "k_hint", "promote_on_device")]
+        "sweep_fp32", "sweep_waves", "sweep_per_cu", "k_hint", "promote_on_device", "gemm_panels", "gemm_blocks")]
 
 
-ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED, ENGINE_TUNED, ENGINE_SWEEP = 0, 1, 2, 3, 4
-ENGINE_NAMES = {0: "stream", 1: "tiles", 2: "shared", 4: "sweep"}
+ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED, ENGINE_TUNED, ENGINE_SWEEP, ENGINE_GEMM = 0, 1, 2, 3, 4, 5
+ENGINE_NAMES = {0: "stream", 1: "tiles", 2: "shared", 4: "sweep", 5: "gemm"}
 
 
 class ReorderingReport(C.Structure):
@@ -145,6 +152,12 @@ HIP_SYMBOLS = {
                                 C.POINTER(TuneReport)]),
     "bsmr_cluster_rows": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float,
                                     C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p]),
+    "bsmr_cluster_rows_sized": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float,
+                                          C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p, C.c_size_t]),
+    "bsmr_plan_tune_sized": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.POINTER(TuneReport), C.c_size_t]),
+    "bsmr_plan_get_tuned": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(TunedChoice)]),
+    "bsmr_plan_set_tuned": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(TunedChoice)]),
     "bsmr_sddmm_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
                                    C.c_void_p]),
     "bsmr_batched_transpose": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -514,13 +527,30 @@ def plan_tune(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, mode=COMPUTE_F16
     r = TuneReport()
     _check(hip().bsmr_plan_tune(plan, K, A_ptr, B_ptr, P_ptr, mode, stream, C.byref(r)), "bsmr_plan_tune")
     out = {"chosen": ENGINE_NAMES[r.chosen_engine], "group": r.chosen_group, "blocks_per_item": r.chosen_blocks_per_item}
-    for name in ("stream_us", "grouped_us", "tiles_us", "shared_us", "fp32_residue_us", "b_only_us", "one_stream_us", "two_streams_us", "convert_pass_us", "fp32_dense_us", "sweep_us", "lowp_call_us", "sweep_fp32_call_us"):
+    for name in ("stream_us", "grouped_us", "tiles_us", "shared_us", "fp32_residue_us", "b_only_us", "one_stream_us", "two_streams_us", "convert_pass_us", "fp32_dense_us", "sweep_us", "lowp_call_us", "sweep_fp32_call_us", "gemm_us"):
         out[name] = round(getattr(r, name), 2)
     out["b_only"], out["overlap"], out["cvt_in_kernel"] = r.chosen_b_only, r.chosen_overlap, r.chosen_cvt_in_kernel
     out["sweep_fp32"] = r.chosen_sweep_fp32
     out["variant"] = VARIANT_NAMES[r.chosen_variant]
     out["variant_us"] = {VARIANT_NAMES[i]: round(r.variant_us[i], 2) for i in range(6) if r.variant_us[i] >= 0}
     return out
+
+
+def plan_get_tuned(plan, K: int, mode=COMPUTE_F16) -> dict:
+    """bsmr_plan_get_tuned: the choice bsmr_plan_tune kept for (K, mode), as a plain dict (JSON-able)"""
+    c = TunedChoice()
+    _check(hip().bsmr_plan_get_tuned(plan, K, mode, C.byref(c)), "bsmr_plan_get_tuned")
+    return {n: getattr(c, n) for n, _ in TunedChoice._fields_ if n != "struct_size"}
+
+
+def plan_set_tuned(plan, K: int, choice: dict, mode=COMPUTE_F16):
+    """bsmr_plan_set_tuned: install a choice measured earlier (plan_get_tuned of another process) without timing anything"""
+    c = TunedChoice()
+    c.struct_size = C.sizeof(TunedChoice)
+    for n, _ in TunedChoice._fields_:
+        if n != "struct_size":
+            setattr(c, n, int(choice[n]))
+    _check(hip().bsmr_plan_set_tuned(plan, K, mode, C.byref(c)), "bsmr_plan_set_tuned")
 
 
 def sddmm_batch(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, num_batches: int, mode=COMPUTE_F16, stream: int = 0):

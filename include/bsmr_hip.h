@@ -212,6 +212,11 @@ typedef struct bsmr_plan_options {
                                        packer without crossing PCIe: -1 = from 2^20 residue entries when the plan's layout
                                        and engine allow, 0 = never, 1 = whenever they allow.  Same plan, byte for byte
                                                                                                          [PROMOTE_ON_DEVICE] */
+    /* device format of the dense part, GEMM engine (fields added in round 4) */
+    int32_t  gemm_panels;           /* row panels per macro-tile: 0 = from the plan's shape (a model of the launch's rounds);
+                                       8, 16                                                                   [GEMM_PANELS] */
+    int32_t  gemm_blocks;           /* 16-column blocks of B per macro-tile: 0 = from the plan's shape; 12, 16, 20 (with 16
+                                       panels), 16, 20 (with 8)                                                 [GEMM_BLOCKS] */
 } bsmr_plan_options;
 int bsmr_plan_options_default(bsmr_plan_options *opt);
 /* defaults, then every BSMR_<NAME> variable that is set */
@@ -241,7 +246,7 @@ int bsmr_plan_build_times(const bsmr_plan *plan, bsmr_plan_build_ms *out);
  * Needs a plan created with dense_engine = BSMR_ENGINE_TUNED; P is overwritten with the (correct) result.  The
  * reference has no counterpart: it tunes (alpha, delta) per matrix by sweeping (src/sddmm.cu:62-118). */
 typedef struct bsmr_tune_report {
-    int32_t chosen_engine;            /* BSMR_ENGINE_STREAM / _TILES / _SHARED / _SWEEP */
+    int32_t chosen_engine;            /* BSMR_ENGINE_STREAM / _TILES / _SHARED / _SWEEP / _GEMM */
     int32_t chosen_group;             /* panels per group of the winner (streaming engine: 1, or 4 = the grouped format;
                                          sweep engine: panels per consumer wave) */
     int32_t chosen_blocks_per_item;   /* shared-B engine: blocks per work item where that was part of the search, else 0;
@@ -269,6 +274,9 @@ typedef struct bsmr_tune_report {
      * microseconds (< 0: not built - the same split as an earlier variant, or no hint), and the one that serves the plan */
     int32_t chosen_variant;           /* BSMR_VARIANT_* */
     float   variant_us[6];
+    /* GEMM engine (round 4; appended): best dense-kernel time on 16-bit operands over the macro-tile shapes tried; when it is
+     * chosen, chosen_group = panels and chosen_blocks_per_item = 16-column blocks per macro-tile */
+    float   gemm_us;
 } bsmr_tune_report;
 #define BSMR_VARIANT_RULES        0   /* the options the plan was created with                                    */
 #define BSMR_VARIANT_AS_RPHM      1   /* the RPHM's split as it is: nothing promoted, nothing folded              */

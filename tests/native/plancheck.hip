@@ -264,3 +264,95 @@ extern "C" int plancheck_sweep(const bsmr_rphm_desc* d, uint32_t W, uint32_t PW,
         if ((wantRow[v] != kNone) != (seen[v] != 0)) return 16;
     return 0;
 }
+
+#include "gemm_format.hpp"
+
+// csrc/gemm_format.hpp read the way denseGemm reads it: every dense entry of the RPHM is listed exactly once, in the
+// (item, wave, pass) list of its macro-tile / panel / column block, with the slab slot of its accumulator cell; the item
+// order is gemmItemPlace's; lists are ordered by (row, column).
+// out[0] items, [1] entries, [2] groups, [3] strips, [4] full grid, [5] bytes, [6] tiles, [7] longest list.
+extern "C" int plancheck_gemm(const bsmr_rphm_desc* d, uint32_t PM, uint32_t NB, uint64_t* out) {
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    bsmr::HostDense hd;
+    int st = bsmr::collectDense(d, hd);
+    if (st != BSMR_OK) return 100 + st;
+    bsmr::GemmFormatHost f;
+    st = bsmr::packGemm(hd, PM, NB, f);
+    if (st != BSMR_OK) return 200 + st;
+    out[0] = f.items.size(); out[1] = hd.entries(); out[2] = f.numGroups; out[3] = f.numStrips; out[4] = f.fullGrid;
+    out[5] = f.bytes(); out[6] = f.numTiles; out[7] = f.maxListWords;
+    std::vector<uint32_t> wantRow(d->nnz, kNone), wantCol(d->nnz, kNone);
+    uint64_t denseEntries = 0;
+    for (uint32_t p = 0; p < d->num_row_panels; ++p)
+        for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b)
+            for (uint32_t i = 0; i < 256; ++i) {
+                const uint32_t v = d->block_values[b * 256 + i];
+                if (v == kNone) continue;
+                const size_t slot = (size_t)p * 16 + i / 16;
+                wantRow[v] = slot < d->num_nonzero_rows ? d->reordered_rows[slot] : kNone;
+                wantCol[v] = d->dense_cols[b * 16 + i % 16];
+                ++denseEntries;
+            }
+    if (hd.entries() != denseEntries) return 1;
+    if (denseEntries == 0) return f.items.empty() ? 0 : 2;
+    const uint32_t TM = PM * 16, m = PM / bsmr::kGemmWavesM, n = NB / bsmr::kGemmWavesN;
+    const uint32_t Q = (m * n + bsmr::kGemmPassTiles - 1) / bsmr::kGemmPassTiles, L = bsmr::kGemmWaves * Q;
+    if (f.passes != Q || f.panelRows.size() != (size_t)f.numGroups * TM) return 3;
+    if (f.rowStart.size() != f.items.size() * TM || f.lists.size() != f.items.size() * (L + 1)) return 4;
+    if (f.fullGrid != (f.items.size() == (size_t)f.numGroups * f.numStrips)) return 5;
+    std::vector<uint8_t> seen(d->nnz, 0);
+    uint64_t expectStart = 0, place = 0;
+    for (size_t it = 0; it < f.items.size(); ++it) {
+        const bsmr::GemmItem& item = f.items[it];
+        if (item.group >= f.numGroups || item.firstBlock % NB || item.firstBlock / NB >= f.numStrips) return 6;
+        if (item.listBase != it * (L + 1)) return 7;
+        // the order of gemmItemPlace, macro-tiles without entries left out
+        for (;; ++place) {
+            if (place >= (uint64_t)f.numGroups * f.numStrips) return 8;
+            uint32_t g, s;
+            bsmr::gemmItemPlace((uint32_t)place, f.numGroups, f.numStrips, g, s);
+            if (g == item.group && s == item.firstBlock / NB) break;
+        }
+        ++place;
+        uint64_t itemEntries = 0;
+        for (uint32_t w = 0; w < bsmr::kGemmWaves; ++w)
+            for (uint32_t q = 0; q < Q; ++q) {
+                const uint32_t b = f.lists[item.listBase + w * Q + q], e = f.lists[item.listBase + w * Q + q + 1];
+                if (b != expectStart || e < b || (e - b) % 4 || e - b > f.maxListWords) return 9;   // lists follow each other, padded to 4
+                expectStart = e;
+                const uint32_t wm = w / bsmr::kGemmWavesN, wn = w % bsmr::kGemmWavesN;
+                uint64_t lastKey = 0;
+                bool padding = false;
+                for (uint32_t i = b; i < e; ++i) {
+                    const uint32_t word = f.words[i];
+                    if (word == bsmr::kGemmNoEntry) {
+                        if (e - i > 3) return 10;   // padding only at the end of a list
+                        padding = true;
+                        continue;
+                    }
+                    if (padding) return 11;
+                    const uint32_t slot = word & 4095u, rw = (word >> 12) & 127u, off = word >> 19;
+                    const uint32_t tp = slot >> 8, lane = (slot >> 2) & 63u, reg = slot & 3u;
+                    const uint32_t t = q * bsmr::kGemmPassTiles + tp;
+                    if (t >= m * n || rw >= m * 16) return 12;
+                    const uint32_t tm = t / n, tn = t % n, r = rw % 16;
+                    if (rw / 16 != tm || reg != (r & 3u) || lane / 16 != r / 4) return 13;   // accumulator layout
+                    const uint32_t c = lane & 15u;
+                    const uint32_t rowInTile = wm * (TM / 2) + rw, colInTile = (wn * n + tn) * 16 + c;
+                    const uint32_t idx = f.rowStart[it * TM + rowInTile] + off;
+                    if (off >= bsmr::kGemmMaxOffset || idx >= d->nnz || seen[idx]++) return 14;
+                    if (f.panelRows[(size_t)item.group * TM + rowInTile] != wantRow[idx]) return 15;
+                    if (item.firstBlock * 16 + colInTile != wantCol[idx]) return 16;
+                    const uint64_t key = ((uint64_t)rw << 32) | colInTile;
+                    if (i > b && key < lastKey) return 17;   // (row, column) order; repeated (row, column) pairs may follow each other
+                    lastKey = key;
+                    ++itemEntries;
+                }
+            }
+        if (itemEntries == 0) return 18;   // macro-tiles without entries are not items
+    }
+    if (f.words.size() < expectStart + bsmr::kGemmWordSlack) return 19;
+    for (uint32_t v = 0; v < d->nnz; ++v)
+        if ((wantRow[v] != kNone) != (seen[v] != 0)) return 20;
+    return 0;
+}

@@ -102,3 +102,25 @@ def test_clusters_running_ahead_give_the_host_order(engine):
         assert stats["passes_ahead"] > 0, stats
         print(f"reddit-like 6000 rows alpha={alpha}: {clusters} clusters, {stats['passes']} passes ({stats['passes_ahead']} ahead), "
               f"{stats['dropped_seeds']} dropped seeds, device {stats['elapsed_ms']:.1f} ms")
+
+
+def test_a_grid_larger_than_the_pass_keeps_the_host_order(engine, monkeypatch):
+    """with many more workgroups than a pass has items (BSMR_CLUSTER_GRID = 65535), workgroups without an
+    item are still being scheduled when the closing workgroup has written the next pass's state.  The state is kept in
+    two copies used in turn (a launch reads one, its closing workgroup writes the other), so such a workgroup sees its
+    own pass's state and leaves: row order and cluster count stay the host implementation's."""
+    monkeypatch.setenv("BSMR_CLUSTER_GRID", "65535")
+    rows, cols, ro, ci = synth.reddit_shard_like(rows=6000, seed=5)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    bw = csr.calculate_block_size(200 << 30)
+    for alpha in (0.3, 0.6):
+        pipe = engine.Pipeline(csr, alpha=alpha, delta=0.3, block_size=bw, device=-1)
+        for _ in range(3):
+            st, perm, clusters, stats = engine.cluster_rows_device(rows, cols, ro, ci, bw, alpha)
+            assert st == engine.OK
+            assert np.array_equal(pipe.array("reorderedRows"), perm) and pipe.num_clusters == clusters, stats
+    rows, cols, ro, ci = synth.mycielskian_pattern(12)
+    for alpha in (0.3,):
+        st, perm, clusters, stats = engine.cluster_rows_device(rows, cols, ro, ci, 16, alpha)
+        pipe = engine.Pipeline(engine.CSR.from_arrays(rows, cols, ro, ci), alpha=alpha, delta=0.3, block_size=16, device=-1)
+        assert st == engine.OK and np.array_equal(pipe.array("reorderedRows"), perm) and pipe.num_clusters == clusters

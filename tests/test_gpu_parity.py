@@ -1040,3 +1040,108 @@ def test_several_shards_on_one_device(engine, oracle, shards):
     r = np.repeat(np.arange(rows), np.diff(ro.astype(np.int64)))
     got, _ = engine.sddmm_operator_sharded(csr, K, hot.ravel(), colid.ravel(), [0] * shards, alpha=0.3, delta=0.1)
     assert np.array_equal(got, (hot[r, 0] + colid[ci, 1]).astype(np.float32))
+
+
+def test_reddit_full_graph_in_eight_shards_on_one_device(engine, oracle, capsys):
+    """BASELINE configs[3] ITSELF through the N > 1 path: the reddit-like graph at full size (232 965^2, 114 618 780 stored
+    entries - reddit's count), K = 256, fp16, cut by cost into EIGHT row ranges, every range its own pipeline + plan
+    (bsmr_sharded_* behind sddmm_multi_gpu), all eight on the one visible device: partition, per-shard plans, rows of A,
+    entry offsets and the gather into the root's P are the 8-GPU code, only the transport of a same-device part is a
+    device-to-device copy instead of an RCCL send / recv (shards own disjoint row panels, hence disjoint entries of P:
+    reference src/BSMR.cpp:678-711).  Checked: the cost partition's imbalance; every entry written (the device P starts as
+    NaN); zero checkData failures against the CPU oracle on all 114.6 M entries; exact placement of every entry with
+    one-hot operands."""
+    import time
+    n, K, shards = 232965, 256, 8
+    t0 = time.perf_counter()
+    deg = synth.reddit_like_degrees(n=n)
+    rows, cols, ro, ci = synth.reddit_like_rows(0, n, n=n, degrees=deg)
+    assert rows == cols == n and ci.size == 114_618_780
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    t_graph = time.perf_counter() - t0
+    bounds = engine.partition_rows_by_cost(csr, shards)
+    assert bounds[0] == 0 and bounds[-1] == n and all(b % 16 == 0 for b in bounds[1:-1])
+    d = np.diff(ro.astype(np.int64))
+    cost = d + 1.5 * (d > 0)
+    per = np.array([cost[bounds[i]:bounds[i + 1]].sum() for i in range(shards)])
+    imbalance = per.max() / per.mean()
+    assert imbalance < 1.02, per                       # cuts at multiples of 16 rows: within 2 % of equal cost
+    A, B = engine.make_data(rows * K, 5489), engine.make_data(cols * K, 5490)
+    t0 = time.perf_counter()
+    got, ms = engine.sddmm_operator_sharded(csr, K, A, B, [0] * shards, alpha=0.3, delta=0.3, iters=2)
+    t_sharded = time.perf_counter() - t0
+    assert ms > 0 and not np.isnan(got).any(), "an entry of P was never written"
+    t0 = time.perf_counter()
+    want = oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B)
+    t_oracle = time.perf_counter() - t0
+    bad, first = oracle.check_data(want, got)
+    assert bad == 0, (bad, first)
+    rel = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-3)))
+    del A, B, want
+    # exact placement: P[e] = f(row) + g(col) with one-hot operands, exact in fp16 x fp16 -> fp32
+    hot = np.zeros((rows, K), dtype=np.float32)
+    hot[:, 0] = np.arange(rows) % 61 + 1
+    hot[:, 1] = 1.0
+    colid = np.zeros((cols, K), dtype=np.float32)
+    colid[:, 0] = 1.0
+    colid[:, 1] = np.arange(cols) % 127
+    placed, _ = engine.sddmm_operator_sharded(csr, K, hot.ravel(), colid.ravel(), [0] * shards, alpha=0.3, delta=0.3)
+    r = np.repeat(np.arange(rows, dtype=np.int64), d)
+    assert np.array_equal(placed, (hot[r, 0] + colid[ci, 1]).astype(np.float32))
+    with capsys.disabled():
+        print(f"\n[configs[3] in {shards} shards on one device] graph {t_graph:.1f} s, pipelines + plans + 3 steps {t_sharded:.1f} s, "
+              f"{ms:.3f} ms per step (8 SDDMMs + gather on ONE GPU), cost imbalance {imbalance:.4f}, oracle {t_oracle:.1f} s, "
+              f"max relative error {rel:.2e}, 0 of {ci.size} entries fail checkData, placement exact")
+
+
+@pytest.mark.shipping_rules
+@pytest.mark.parametrize("name,delta", [("configs[4] dlmc-like 4096^2 K=512 bf16", 0.0), ("configs[4] dlmc-like 4096^2 K=512 bf16", 0.1),
+                                        ("configs[1] nips-like K=128 fp16", 0.0), ("nips-like K=512 fp16", 0.0)])
+def test_full_size_parity_of_tuned_plans(engine, oracle, capsys, name, delta):
+    """The engines the bench lines are quoted on, at full size: the plan created TUNABLE, bsmr_plan_tune on the operands,
+    then the tuned call against the oracle - checkData with zero failures (reference include/checkData.hpp:14-30), the
+    dense-path error model, no entry unwritten - and against the untuned (streaming) call: bit for bit the same values,
+    whichever engine won (all dense engines round and accumulate alike)."""
+    if name.startswith("configs[4]"):
+        rows, cols, ro, ci = synth.bernoulli()
+        K, mode = 512, engine.COMPUTE_BF16
+    else:
+        rows, cols, ro, ci = synth.nips_like()
+        K, mode = (128 if "K=128" in name else 512), engine.COMPUTE_F16
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    arrays = engine.Pipeline(csr, alpha=0.3, delta=delta, device=-1).arrays()
+    st, plan = engine.plan_from_arrays(rows, cols, csr.nnz, arrays, device=0, options=engine.plan_options(dense_engine=engine.ENGINE_TUNED))
+    assert st == engine.OK
+    dev = _dev()
+    A, B = engine.make_data(rows * K, 5489), engine.make_data(cols * K, 5490)
+    tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    tP = torch.full((csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+    engine.sddmm(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), mode, 0)          # untuned: streams
+    torch.cuda.synchronize()
+    untuned = tP.cpu().numpy()
+    report = engine.plan_tune(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), mode, 0)
+    tP.fill_(float("nan"))
+    engine.sddmm(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), mode, 0)          # tuned
+    torch.cuda.synchronize()
+    got = tP.cpu().numpy()
+    stats = engine.PlanStats()
+    engine.hip().bsmr_plan_get_stats(plan, stats)
+    engine.plan_destroy(plan)
+    assert not np.isnan(got).any(), "some stored entry was never written"
+    want = oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B)
+    bad, first = oracle.check_data(want, got)
+    assert bad == 0, (bad, first)
+    rel = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-3)))
+    assert rel < 1e-3
+    model = oracle.dense_lowp_model(2 if mode == 0 else 3, rows, K, ro, ci, A, B)
+    absdot = oracle.sddmm_f64(rows, K, ro, ci, np.abs(A), np.abs(B))
+    err = np.abs(got.astype(np.float64) - model)
+    bound = (K / 16 + 8) * 2.0 ** -23          # (the looser of the dense and the 16-bit residue bounds)
+    assert (err <= bound * absdot + 1e-30).all(), f"error against the rounded-operand model {err.max()}"
+    if report["cvt_in_kernel"] != 1 or stats.num_sparse_entries == 0:
+        assert np.array_equal(got.view(np.uint32), untuned.view(np.uint32)), "tuned and untuned calls differ"
+    with capsys.disabled():
+        times = {k: v for k, v in report.items() if k.endswith("_us") and isinstance(v, float) and v >= 0}
+        print(f"\n[{name}, delta={delta}] chosen={report['chosen']} group={report['group']} blocks={report['blocks_per_item']} "
+              f"cvt_in_kernel={report['cvt_in_kernel']}; dense kernel us per engine {times}; max relative error {rel:.3e} "
+              f"(tolerance 1e-3), dense entries {stats.num_dense_entries}, residue {stats.num_sparse_entries}")

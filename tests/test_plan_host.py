@@ -228,3 +228,82 @@ def test_sweep_format_rejects_shapes_it_cannot_hold(sweepcheck):
     assert sweepcheck(rows, cols, ro, ci, 0.3, 0.0, 3, 4)[0] == 201      # panels per wave: 1, 2 or 4
     assert sweepcheck(rows, cols, ro, ci, 0.3, 0.0, 2, 64)[0] == 201     # at most 63 blocks per strip
     assert sweepcheck(rows, cols, ro, ci, 0.3, 0.0, 2, 8, waves=6)[0] == 201   # 4 or 8 consumer waves
+
+
+@pytest.fixture(scope="module")
+def gemmcheck(engine):
+    lib = C.CDLL(str(REPO / "tests" / "native" / "libplancheck.so"))
+    lib.plancheck_gemm.restype = C.c_int
+    lib.plancheck_gemm.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+
+    def run(rows, cols, ro, ci, alpha, delta, panels, blocks):
+        csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+        pipe = engine.Pipeline(csr, alpha=alpha, delta=delta, device=-1)
+        arrays = pipe.arrays()
+        keep = {k: np.ascontiguousarray(arrays[k], dtype=np.uint32) for k in
+                ("reorderedRows", "denseCols", "blockOffsets", "blockValues", "sparseValueOffsets",
+                 "sparseValues", "sparseRelativeRows", "sparseColIndices")}
+        d = engine.RphmDesc()
+        d.M, d.N, d.nnz = rows, cols, csr.nnz
+        d.num_nonzero_rows = keep["reorderedRows"].size
+        d.num_row_panels = keep["blockOffsets"].size - 1
+        cast = lambda a: a.ctypes.data_as(engine.u32p)
+        d.reordered_rows, d.dense_cols = cast(keep["reorderedRows"]), cast(keep["denseCols"])
+        d.block_offsets, d.block_values = cast(keep["blockOffsets"]), cast(keep["blockValues"])
+        d.sparse_value_offsets, d.sparse_values = cast(keep["sparseValueOffsets"]), cast(keep["sparseValues"])
+        d.sparse_relative_rows, d.sparse_col_indices = cast(keep["sparseRelativeRows"]), cast(keep["sparseColIndices"])
+        out = (C.c_uint64 * 8)()
+        rc = lib.plancheck_gemm(C.byref(d), panels, blocks, out)
+        res = dict(zip(("items", "entries", "groups", "strips", "full_grid", "bytes", "tiles", "longest_list"), (int(v) for v in out)))
+        res["rphm_dense"] = int(csr.nnz - keep["sparseValues"].size)
+        return rc, res
+    return run
+
+
+@pytest.mark.parametrize("panels,blocks", [(16, 16), (16, 20), (16, 12), (8, 16), (8, 20), (16, 8), (8, 8), (8, 12)])
+def test_gemm_format_lists_every_dense_entry_once(gemmcheck, panels, blocks):
+    """csrc/gemm_format.hpp, read the way denseGemm reads it: each dense entry of the RPHM once, in the list of its
+    (macro-tile, wave, pass), with the accumulator cell of its (row, column); items in gemmItemPlace's order; lists in
+    (row, column) order - all-dense and hybrid plans, a ragged last row group (21 panels) and a ragged last column
+    block (1500 = 93 * 16 + 12)."""
+    rows, cols, ro, ci = synth.nips_like(rows=330, cols=1500, nnz=42000, seed=3)
+    for delta in (0.0, 0.1):
+        rc, r = gemmcheck(rows, cols, ro, ci, 0.3, delta, panels, blocks)
+        assert rc == 0, f"invariant {rc} violated: {r}"
+        assert r["entries"] == r["rphm_dense"] > 0
+        assert r["groups"] == -(-21 // panels) and r["strips"] == -(-94 // blocks)
+        assert r["items"] <= r["groups"] * r["strips"] and r["full_grid"] == (r["items"] == r["groups"] * r["strips"])
+        assert r["tiles"] == r["items"] * panels * blocks
+
+
+def test_gemm_format_takes_unsorted_rows_full_tiles_and_empty_macro_tiles(gemmcheck):
+    """CSR rows in file order (the reference's loader keeps it): the entry words carry explicit offsets, so the format
+    does not need sorted rows; a full matrix makes lists of 4096 words per pass; macro-tiles without a dense entry are
+    left out of the item list (the kernel then takes an item's place from its record)."""
+    rng = np.random.default_rng(5)
+    rows, cols, ro, ci = synth.random_pattern(150, 220, 5000, seed=11, empty_rows=9)
+    ci = ci.copy()
+    for i in range(rows):
+        rng.shuffle(ci[ro[i]:ro[i + 1]])
+    rc, r = gemmcheck(rows, cols, ro, ci, 0.3, 0.0, 8, 8)
+    assert rc == 0 and r["entries"] == ci.size, (rc, r)
+    rows, cols = 256, 256
+    ro = np.arange(rows + 1, dtype=np.uint32) * cols
+    ci = np.tile(np.arange(cols, dtype=np.uint32), rows)
+    rc, r = gemmcheck(rows, cols, ro, ci, 0.3, 0.0, 16, 16)
+    assert rc == 0 and r["longest_list"] == 4096 and r["items"] == 1, (rc, r)
+    # a block-diagonal pattern: off-diagonal macro-tiles hold nothing
+    blocks = [(i, j) for i in range(600) for j in range((i // 150) * 400, (i // 150) * 400 + 400, 7)]
+    ro = np.zeros(601, dtype=np.uint32)
+    for i, _ in blocks:
+        ro[i + 1] += 1
+    ro = np.cumsum(ro).astype(np.uint32)
+    ci = np.array([j for _, j in blocks], dtype=np.uint32)
+    rc, r = gemmcheck(600, 1600, ro, ci, 0.3, 0.0, 8, 8)
+    assert rc == 0 and r["full_grid"] == 0 and 0 < r["items"] < r["groups"] * r["strips"], (rc, r)
+
+
+def test_gemm_format_rejects_shapes_it_cannot_hold(gemmcheck):
+    rows, cols, ro, ci = synth.random_pattern(40, 60, 500, seed=2)
+    assert gemmcheck(rows, cols, ro, ci, 0.3, 0.0, 12, 16)[0] == 201     # panels per macro-tile: 8 or 16
+    assert gemmcheck(rows, cols, ro, ci, 0.3, 0.0, 16, 24)[0] == 201     # blocks per macro-tile: 8, 12, 16, 20

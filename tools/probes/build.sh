@@ -5,4 +5,6 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Ibsmr-sddmm_amd/csrc"
 /opt/rocm/bin/hipcc $F -o tools/probes/sweep_probe tools/probes/sweep_probe.hip &
 /opt/rocm/bin/hipcc $F -DBSMR_SWEEP_STAMPS -o tools/probes/sweep_probe_stamps tools/probes/sweep_probe.hip &
 /opt/rocm/bin/hipcc $F -o tools/probes/stream_probe tools/probes/stream_probe.hip &
+/opt/rocm/bin/hipcc $F -o tools/probes/gemm_probe tools/probes/gemm_probe.hip &
+/opt/rocm/bin/hipcc $F -DBSMR_GEMM_LAB -o tools/probes/gemm_probe_lab tools/probes/gemm_probe.hip &
 wait

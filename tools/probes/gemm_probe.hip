@@ -28,11 +28,11 @@
 using bsmr::GemmItem;
 #ifdef BSMR_GEMM_LAB
 typedef void (*Kernel)(const uint16_t*, const uint16_t*, uint32_t, uint32_t, const uint32_t*, const GemmItem*, const uint32_t*,
-                       const uint32_t*, const uint32_t*, float*, uint32_t, bsmr::Batch, uint32_t);
+                       const uint32_t*, const uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, bsmr::Batch, uint32_t);
 #define LAB_ARGS , skip
 #else
 typedef void (*Kernel)(const uint16_t*, const uint16_t*, uint32_t, uint32_t, const uint32_t*, const GemmItem*, const uint32_t*,
-                       const uint32_t*, const uint32_t*, float*, uint32_t, bsmr::Batch);
+                       const uint32_t*, const uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, bsmr::Batch);
 #define LAB_ARGS
 #endif
 struct Variant {
@@ -43,8 +43,10 @@ struct Variant {
 #define V(name, KT, PM, NB, MODE) {name, KT, PM, NB, MODE, bsmr::denseGemm<KT, PM, NB, MODE>}
 static const Variant kVariants[] = {
     V("k512_b_256x256", 8, 16, 16, 1), V("k512_b_128x256", 8, 8, 16, 1), V("k512_b_256x128", 8, 16, 8, 1),
+    V("k512_b_256x320", 8, 16, 20, 1), V("k512_b_256x192", 8, 16, 12, 1), V("k512_b_128x320", 8, 8, 20, 1),
     V("k256_h_256x256", 4, 16, 16, 0), V("k128_h_256x256", 2, 16, 16, 0), V("k128_h_128x256", 2, 8, 16, 0),
-    V("k128_h_256x128", 2, 16, 8, 0),
+    V("k128_h_256x128", 2, 16, 8, 0), V("k128_h_256x320", 2, 16, 20, 0), V("k128_h_256x192", 2, 16, 12, 0),
+    V("k64_h_256x256", 1, 16, 16, 0),
 };
 
 static uint16_t toF16(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
@@ -135,9 +137,10 @@ int main(int argc, char** argv) {
     const size_t lds = bsmr::gemmLdsBytes(v->PM, v->NB);
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(v->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const bsmr::Batch batch{0, 0, 0, 1};
+    const uint32_t full = f.fullGrid && !getenv("GEMM_ITEMS") ? 1u : 0u;   // GEMM_ITEMS=1: take the places from the item records
     auto launch = [&]() {
         hipLaunchKernelGGL(v->kernel, dim3((uint32_t)f.items.size()), dim3(512), lds, nullptr, dA, dB, (uint32_t)(A16.size() * 2),
-                           (uint32_t)(B16.size() * 2), dRows, dItems, dRowStart, dLists, dWords, dP, N, batch LAB_ARGS);
+                           (uint32_t)(B16.size() * 2), dRows, dItems, dRowStart, dLists, dWords, dP, N, f.numGroups, f.numStrips, full, batch LAB_ARGS);
     };
     launch();
     CHECK(hipGetLastError());

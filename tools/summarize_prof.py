@@ -37,17 +37,25 @@ out = {"bench": {k: bench[k] for k in ("value", "ms_per_step", "kernels_ms", "ro
 # HBM traffic of the dominant kernel, per launch: FETCH_SIZE / WRITE_SIZE are in KiB; gfx950
 # FETCH_SIZE counts half of a 16-B-per-lane stream (MI355X_MICROARCH.md "HBM"), so it is doubled.
 dom = bench["roofline"]["kernel"]
-names = {"dense": ("denseStream", "denseGroups", "denseTiles", "denseShared", "denseSweep"), "sparse": ("sparseEntries",), "convert": ("convertOperands",)}[dom]
-# (a tuned run launches every candidate engine a few times - more often than the steps of a short counter pass: the steps'
-# kernel is an instantiation of the engine the bench line names)
+names = {"dense": ("denseStream", "denseGroups", "denseTiles", "denseShared", "denseSweep", "denseGemm"), "sparse": ("sparseEntries",), "convert": ("convertOperands",)}[dom]
+# the steps' kernel is an instantiation of the engine the bench line names; the profiler passes REPLAY the line's tuned choice
+# (tools/profile_bench.sh), so that kernel is launched by the steps and the warm-up alone - no candidate engines beside it
 chosen = (bench.get("dense_engine") or {}).get("chosen")
-if dom == "dense" and chosen in ("stream", "tiles", "shared", "sweep"):
-    names = {"stream": ("denseStream", "denseGroups"), "tiles": ("denseTiles",), "shared": ("denseShared",), "sweep": ("denseSweep",)}[chosen]
-# (a tuned run launches every candidate engine a few times: the steps' kernel is the one with the most launches)
-trace_ms = {r["Name"].split("(")[0].replace("void ", ""): float(r["AverageNs"]) / 1e6 for r in csv.DictReader(open(stats))}
-want_ms = bench["kernels_ms"].get(f"{dom}_ms", 0.0)
-# ... and of its instantiations the one whose traced duration is closest to the bench line's kernel time
-matching = [(-abs(trace_ms.get(k, 1e9) - want_ms), k) for k, c in pmc.items() if any(n in k for n in names) and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
+if dom == "dense" and chosen in ("stream", "tiles", "shared", "sweep", "gemm"):
+    names = {"stream": ("denseStream", "denseGroups"), "tiles": ("denseTiles",), "shared": ("denseShared",), "sweep": ("denseSweep",), "gemm": ("denseGemm",)}[chosen]
+rows = list(csv.DictReader(open(stats)))
+calls = {r["Name"].split("(")[0].replace("void ", ""): int(r["Calls"]) for r in rows}
+out["launches_in_kernel_trace"] = {k: v for k, v in calls.items() if "bsmr::" in k}
+# of its instantiations the one with the most launches in the kernel trace: the steps' (200 + 20 warm-up; bench.py's event-timed
+# passes add more)
+candidates = [k for k in pmc if any(n in k for n in names) and "FETCH_SIZE" in pmc[k] and "WRITE_SIZE" in pmc[k]]
+matching = [(calls.get(k, 0), k) for k in candidates]
+if matching:
+    top = max(matching)
+    assert top[0] >= 220, f"the step kernel {top[1]} has {top[0]} launches in the kernel trace: fewer than steps + warm-up"
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        assert pmc[top[1]][c]["launches"] >= 25, f"{c} pass: {pmc[top[1]][c]['launches']} launches of {top[1]}"
+    out["step_kernel"] = {"name": top[1], "launches": top[0], "average_ns": next(float(r["AverageNs"]) for r in rows if r["Name"].split("(")[0].replace("void ", "") == top[1])}
 for k, c in pmc.items():
     if matching and k == max(matching)[1]:
         traffic = int((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
