@@ -1211,14 +1211,22 @@ int launchSweep(const bsmr_plan* p, uint32_t K, const void* A, const void* B, fl
 // ---- GEMM engine (csrc/gemm_format.hpp, csrc/gemm_kernels.hpp) -------------------------------------------
 // K in slices of 64; the 16-bit copies only (A and B addressed through 32-bit buffer offsets: below 4 GiB each)
 inline bool gemmServesK(uint32_t K) { return K == 64 || K == 128 || K == 256 || K == 512; }
-inline bool gemmFp32ServesK(uint32_t) { return false; }
-inline bool gemmFits(const bsmr_plan* p, uint32_t K) {
-    return (uint64_t)p->M * K * 2ull < (1ull << 32) && (uint64_t)p->N * K * 2ull < (1ull << 32);
+// ... or, for K <= 128, the caller's fp32 operands rounded in the kernel (slices of 32 k; K = 32 is the streaming kernel's)
+inline bool gemmFp32ServesK(uint32_t K) { return K == 64 || K == 128; }
+inline bool gemmFits(const bsmr_plan* p, uint32_t K, uint32_t elemBytes = 2) {
+    return (uint64_t)p->M * K * elemBytes < (1ull << 32) && (uint64_t)p->N * K * elemBytes < (1ull << 32);
 }
 inline bool gemmWanted(const bsmr_plan* p, uint32_t K) {
     return p->useGemm && gemmServesK(K) && gemmFits(p, K) && p->hostDense.entries() != 0;
 }
 inline bool gemmEngine(const bsmr_plan* p) { return p->gemmNow >= 0; }
+// fp32 operands rounded in the kernel: what bsmr_plan_tune measured for the call, else the option (by default: plans without
+// a residue - the residue of such a call runs its fp32 kernel)
+inline bool gemmFp32(const bsmr_plan* p, uint32_t K) {
+    if (!gemmFp32ServesK(K) || !gemmFits(p, K, 4)) return false;
+    if (p->cvtNow >= 0) return p->cvtNow == 1;
+    return p->opt.gemm_fp32 > 0 || (p->opt.gemm_fp32 < 0 && p->numSparseItems == 0);
+}
 // The macro-tile shapes the kernels are built for (panels x 16-column blocks), best first for a full chip.
 constexpr uint32_t kGemmShapes[][2] = {{16, 16}, {16, 20}, {16, 12}, {8, 16}, {8, 20}};
 // Modelled time of a launch in microseconds (probe numbers, tools/probes/gemm_probe.hip: 4096^2 K = 512 17.1 us with 256
@@ -1230,6 +1238,11 @@ inline double gemmModelUs(const bsmr_plan* p, uint32_t K, uint32_t PM, uint32_t 
     const double slice = 1.4 * (PM * NB / 256.0) * (PM * NB < 256 ? 1.15 : 1.0) * perCu;   // (smaller tiles move more bytes per MFMA)
     return 2.0 + rounds * (4.0 + slice * (K / 64.0));
 }
+inline bool gemmShapeBuilt(uint32_t PM, uint32_t NB, bool fp32 = false) {
+    for (const auto& sh : kGemmShapes)
+        if (sh[0] == PM && sh[1] == NB) return !(fp32 && NB == 12);   // (the fp32-operand kernels: four shapes)
+    return false;
+}
 void gemmShape(const bsmr_plan* p, uint32_t K, uint32_t& PM, uint32_t& NB, int rank = 0) {
     const int forcedPM = p->gemmPanelsNow > 0 ? p->gemmPanelsNow : p->opt.gemm_panels;
     const int forcedNB = p->gemmBlocksNow > 0 ? p->gemmBlocksNow : p->opt.gemm_blocks;
@@ -1240,17 +1253,14 @@ void gemmShape(const bsmr_plan* p, uint32_t K, uint32_t& PM, uint32_t& NB, int r
     }
     // the rank-th best shape by the model
     std::vector<std::pair<double, uint32_t>> order;
+    const bool fp32 = gemmFp32(p, K);
     for (uint32_t i = 0; i < sizeof(kGemmShapes) / sizeof(kGemmShapes[0]); ++i)
-        order.push_back({gemmModelUs(p, K, kGemmShapes[i][0], kGemmShapes[i][1]), i});
+        if (gemmShapeBuilt(kGemmShapes[i][0], kGemmShapes[i][1], fp32))
+            order.push_back({gemmModelUs(p, K, kGemmShapes[i][0], kGemmShapes[i][1]), i});
     std::stable_sort(order.begin(), order.end());
     const uint32_t pick = order[std::min<size_t>((size_t)rank, order.size() - 1)].second;
     PM = kGemmShapes[pick][0];
     NB = kGemmShapes[pick][1];
-}
-inline bool gemmShapeBuilt(uint32_t PM, uint32_t NB) {
-    for (const auto& sh : kGemmShapes)
-        if (sh[0] == PM && sh[1] == NB) return true;
-    return false;
 }
 
 // sets p->gemmNow to the format of the call's shape, building it on first use; -1 when the shape cannot be packed
@@ -1258,7 +1268,7 @@ int ensureGemm(bsmr_plan* p, uint32_t K) {
     uint32_t PM, NB;
     gemmShape(p, K, PM, NB);
     p->gemmNow = -1;
-    if (!gemmShapeBuilt(PM, NB)) return BSMR_OK;
+    if (!gemmShapeBuilt(PM, NB, gemmFp32(p, K))) return BSMR_OK;
     for (size_t i = 0; i < p->gemms.size(); ++i)
         if (p->gemms[i].PM == PM && p->gemms[i].NB == NB) {
             if (p->gemms[i].usable) p->gemmNow = (int)i;
@@ -1303,39 +1313,48 @@ int ensureGemm(bsmr_plan* p, uint32_t K) {
     }
 }
 
-template <int KT, int PM, int NB, int MODE>
-int launchGemmT(const GemmFormatDev& w, const bsmr_plan* p, const uint16_t* A16, const uint16_t* B16, float* P, const Queue& s) {
-    auto kernel = bsmr::denseGemm<KT, PM, NB, MODE>;
+template <int KT, int PM, int NB, int MODE, bool SRC32>
+int launchGemmT(const GemmFormatDev& w, const bsmr_plan* p, const void* A, const void* B, float* P, const Queue& s) {
+    auto kernel = bsmr::denseGemm<KT, PM, NB, MODE, SRC32>;
     const size_t lds = bsmr::gemmLdsBytes(PM, NB);
     if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, p->device)) return st;
-    const uint32_t K = 64u * KT;
-    hipLaunchKernelGGL(kernel, dim3(w.numItems, s.batch.count), dim3(bsmr::kGemmWaves * bsmr::kWave), lds, s, A16, B16,
-                       (uint32_t)((uint64_t)p->M * K * 2ull), (uint32_t)((uint64_t)p->N * K * 2ull), w.panelRows, w.items, w.rowStart, w.lists,
+    const uint64_t K = (SRC32 ? 32u : 64u) * KT, esz = SRC32 ? 4 : 2;
+    hipLaunchKernelGGL(kernel, dim3(w.numItems, s.batch.count), dim3(bsmr::kGemmWaves * bsmr::kWave), lds, s, A, B,
+                       (uint32_t)((uint64_t)p->M * K * esz), (uint32_t)((uint64_t)p->N * K * esz), w.panelRows, w.items, w.rowStart, w.lists,
                        w.words, P, p->N, w.numGroups, w.numStrips, w.fullGrid ? 1u : 0u, s.batch);
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
-template <int KT, int MODE>
-int launchGemmS(const GemmFormatDev& w, const bsmr_plan* p, const uint16_t* A16, const uint16_t* B16, float* P, const Queue& s) {
+template <int KT, int MODE, bool SRC32>
+int launchGemmS(const GemmFormatDev& w, const bsmr_plan* p, const void* A, const void* B, float* P, const Queue& s) {
     switch (w.PM * 100 + w.NB) {
-    case 1616: return launchGemmT<KT, 16, 16, MODE>(w, p, A16, B16, P, s);
-    case 1620: return launchGemmT<KT, 16, 20, MODE>(w, p, A16, B16, P, s);
-    case 1612: return launchGemmT<KT, 16, 12, MODE>(w, p, A16, B16, P, s);
-    case 816: return launchGemmT<KT, 8, 16, MODE>(w, p, A16, B16, P, s);
-    case 820: return launchGemmT<KT, 8, 20, MODE>(w, p, A16, B16, P, s);
+    case 1616: return launchGemmT<KT, 16, 16, MODE, SRC32>(w, p, A, B, P, s);
+    case 1620: return launchGemmT<KT, 16, 20, MODE, SRC32>(w, p, A, B, P, s);
+    case 816: return launchGemmT<KT, 8, 16, MODE, SRC32>(w, p, A, B, P, s);
+    case 820: return launchGemmT<KT, 8, 20, MODE, SRC32>(w, p, A, B, P, s);
+    case 1612:
+        if constexpr (!SRC32) return launchGemmT<KT, 16, 12, MODE, false>(w, p, A, B, P, s);
+        return BSMR_ERR_INVALID_ARG;
     default: return BSMR_ERR_INVALID_ARG;
     }
 }
+// src32: A and B are the caller's fp32 operands; otherwise the 16-bit copies
 template <int MODE>
-int launchGemm(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P, const Queue& s) {
+int launchGemm(const bsmr_plan* p, uint32_t K, const void* A, const void* B, float* P, const Queue& s, bool src32) {
     const GemmFormatDev& w = p->gemms[(size_t)p->gemmNow];
     if (w.numItems == 0) return BSMR_OK;
-    // (a batched call strides the operands by the batch index: every problem of the batch must stay below 4 GiB of offsets)
+    if (src32) {
+        switch (K) {
+        case 64: return launchGemmS<2, MODE, true>(w, p, A, B, P, s);
+        case 128: return launchGemmS<4, MODE, true>(w, p, A, B, P, s);
+        default: return BSMR_ERR_INVALID_ARG;
+        }
+    }
     switch (K) {
-    case 64: return launchGemmS<1, MODE>(w, p, A16, B16, P, s);
-    case 128: return launchGemmS<2, MODE>(w, p, A16, B16, P, s);
-    case 256: return launchGemmS<4, MODE>(w, p, A16, B16, P, s);
-    case 512: return launchGemmS<8, MODE>(w, p, A16, B16, P, s);
+    case 64: return launchGemmS<1, MODE, false>(w, p, A, B, P, s);
+    case 128: return launchGemmS<2, MODE, false>(w, p, A, B, P, s);
+    case 256: return launchGemmS<4, MODE, false>(w, p, A, B, P, s);
+    case 512: return launchGemmS<8, MODE, false>(w, p, A, B, P, s);
     default: return BSMR_ERR_INVALID_ARG;
     }
 }
@@ -1350,7 +1369,7 @@ inline bool streamCvtServes(const DenseFormat& f, uint32_t K) {
 // nips-like K=32 9.3 -> 7.4 us, mycielskian14 K=32 13.3 -> 11.3; mycielskian15 K=32, 1.8 M gathered columns: 26.6 vs
 // 27.1 in the bench loop; with a residue the choice is left to the tuner, because the residue then runs its fp32 kernel).
 inline bool cvtInKernel(const bsmr_plan* p, uint32_t K) {
-    if (gemmEngine(p)) return false;   // (the GEMM engine reads the 16-bit copies)
+    if (gemmEngine(p)) return gemmFp32(p, K);
     if (sweepEngine(p)) return sweepFp32(p, K);
     if (p->cvtNow >= 0) return p->cvtNow == 1;
     // (the fp32 gather moves unionColumns x K x 2 bytes more, at ~12 TB/s, against ~4.5 us of pass + boundary saved)
@@ -1368,7 +1387,7 @@ inline bool tilesEngine(const bsmr_plan* p, uint32_t K) {
 template <int MODE>
 int launchDense16(const bsmr_plan* p, uint32_t K, const uint16_t* A16, const uint16_t* B16, float* P,
                   const Queue& s) {
-    if (gemmEngine(p)) return launchGemm<MODE>(p, K, A16, B16, P, s);
+    if (gemmEngine(p)) return launchGemm<MODE>(p, K, A16, B16, P, s, false);
     if (sweepEngine(p)) return launchSweep<MODE>(p, K, A16, B16, P, s, false);
     if (tilesEngine(p, K)) return launchTiles<MODE>(p, K, A16, B16, P, s);
     const DenseFormat& f = chooseFormat(p, K);
@@ -1427,6 +1446,7 @@ int launchStreamCvtT(const DenseFormat& f, const float* A, const float* B, const
 
 template <int MODE>
 int launchDenseCvt(const bsmr_plan* p, uint32_t K, const float* A, const float* B, float* P, const Queue& s) {
+    if (gemmEngine(p)) return launchGemm<MODE>(p, K, A, B, P, s, true);
     if (sweepEngine(p)) return launchSweep<MODE>(p, K, A, B, P, s, true);
     const DenseFormat& f = p->fmt[0];
     if (f.numItems == 0) return BSMR_OK;
@@ -1842,6 +1862,7 @@ int bsmr_plan_options_default(bsmr_plan_options* opt) {
     o.promote_on_device = -1;
     o.gemm_panels = 0;
     o.gemm_blocks = 0;
+    o.gemm_fp32 = -1;
     *opt = o;
     return BSMR_OK;
 }
@@ -1870,7 +1891,7 @@ int bsmr_plan_options_from_env(bsmr_plan_options* opt) {
         {"BSMR_MASK_TILES", &o.mask_tiles}, {"BSMR_PACK_ON_DEVICE", &o.pack_on_device},
         {"BSMR_SWEEP_PANELS", &o.sweep_panels}, {"BSMR_SWEEP_BLOCKS", &o.sweep_strip_blocks}, {"BSMR_SWEEP_FP32", &o.sweep_fp32},
         {"BSMR_SWEEP_WAVES", &o.sweep_waves}, {"BSMR_SWEEP_PER_CU", &o.sweep_per_cu}, {"BSMR_K_HINT", &o.k_hint}, {"BSMR_PROMOTE_ON_DEVICE", &o.promote_on_device},
-        {"BSMR_GEMM_PANELS", &o.gemm_panels}, {"BSMR_GEMM_BLOCKS", &o.gemm_blocks},
+        {"BSMR_GEMM_PANELS", &o.gemm_panels}, {"BSMR_GEMM_BLOCKS", &o.gemm_blocks}, {"BSMR_GEMM_FP32", &o.gemm_fp32},
     };
     for (const auto& k : knobs) *k.field = envInt(k.name, *k.field);
     return BSMR_OK;
@@ -2600,7 +2621,8 @@ int tuneEngines(bsmr_plan* plan, uint32_t K, const float* A, const float* B, flo
     r.chosen_cvt_in_kernel = -1;
     r.convert_pass_us = r.fp32_dense_us = -1.f;
     r.sweep_us = r.lowp_call_us = r.sweep_fp32_call_us = -1.f;
-    r.gemm_us = -1.f;
+    r.gemm_us = r.gemm_fp32_call_us = -1.f;
+    r.chosen_gemm_fp32 = 0;
     r.chosen_sweep_fp32 = 0;
     BSMR_HIP(hipSetDevice(plan->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2672,6 +2694,7 @@ int tuneEngines(bsmr_plan* plan, uint32_t K, const float* A, const float* B, flo
             for (int rank = 0; rank < 2; ++rank) {
                 uint32_t PM, NB;
                 plan->gemmPanelsNow = plan->gemmBlocksNow = 0;
+                plan->cvtNow = 0;   // (the shapes of the 16-bit kernels)
                 gemmShape(plan, K, PM, NB, rank);
                 if (PM == seenPM && NB == seenNB) continue;
                 seenPM = PM;
@@ -2774,6 +2797,42 @@ int tuneEngines(bsmr_plan* plan, uint32_t K, const float* A, const float* B, flo
             r.chosen_sweep_fp32 = 1;
         }
     }
+    // 6. K = 64 / 128: the best of the above as a whole call against the GEMM kernel on the caller's fp32 operands (no
+    //    conversion pass, one launch; a residue then runs its fp32 kernel), over the two macro-tile shapes its model ranks first
+    if (st == BSMR_OK && lowp && gemmFp32ServesK(K) && gemmFits(plan, K, 4) && plan->fmt[0].numItems && !plan->convertInKernel && sweepApplies(plan)) {
+        float callUs = r.lowp_call_us;
+        if (r.chosen_sweep_fp32 && r.sweep_fp32_call_us >= 0.f) callUs = r.sweep_fp32_call_us;
+        if (callUs < 0.f) st = timeChoice(best, 7, callUs);
+        bsmr_plan::Tuned f = best, bestF = best;
+        f.engine = BSMR_ENGINE_GEMM;
+        f.format = -1;
+        f.cvt = 1;
+        f.waves = 0;
+        uint32_t seenPM = 0, seenNB = 0;
+        for (int rank = 0; rank < 2 && st == BSMR_OK; ++rank) {
+            uint32_t PM, NB;
+            plan->gemmPanelsNow = plan->gemmBlocksNow = 0;
+            plan->cvtNow = 1;
+            gemmShape(plan, K, PM, NB, rank);
+            if (PM == seenPM && NB == seenNB) continue;
+            seenPM = PM;
+            seenNB = NB;
+            f.group = (int)PM;
+            f.blocksPerItem = (int)NB;
+            float us = -1.f;
+            st = timeChoice(f, 7, us);
+            if (st == BSMR_OK && us >= 0.f && (r.gemm_fp32_call_us < 0.f || us < r.gemm_fp32_call_us)) {
+                r.gemm_fp32_call_us = us;
+                bestF = f;
+            }
+        }
+        if (st == BSMR_OK && callUs >= 0.f && r.gemm_fp32_call_us >= 0.f && r.gemm_fp32_call_us < callUs * kTuneMargin) {
+            best = bestF;
+            r.chosen_sweep_fp32 = 0;
+            r.chosen_gemm_fp32 = 1;
+        }
+        if (r.lowp_call_us < 0.f) r.lowp_call_us = callUs;
+    }
     if (st != BSMR_OK) {
         plan->tuned.erase(key);
         return st;
@@ -2873,7 +2932,7 @@ int bsmr_plan_set_tuned(bsmr_plan* plan, uint32_t K, int mode, const bsmr_tuned_
     if ((t.engine == BSMR_ENGINE_TILES || t.engine == BSMR_ENGINE_SHARED) && (!tilesServeK(K) || plan->hostDense.entries() == 0)) return BSMR_ERR_BAD_PLAN;
     if (t.engine == BSMR_ENGINE_SWEEP && (!sweepServesK(K) || plan->hostDense.entries() == 0)) return BSMR_ERR_BAD_PLAN;
     if (t.engine == BSMR_ENGINE_GEMM && (!gemmServesK(K) || plan->hostDense.entries() == 0)) return BSMR_ERR_BAD_PLAN;
-    if (t.cvt == 1 && !(t.engine == BSMR_ENGINE_SWEEP ? K <= 128 : t.engine == BSMR_ENGINE_GEMM ? gemmFp32ServesK(K) : streamCvtServes(plan->fmt[0], K)))
+    if (t.cvt == 1 && !(t.engine == BSMR_ENGINE_SWEEP ? K <= 128 : t.engine == BSMR_ENGINE_GEMM ? (gemmFp32ServesK(K) && gemmFits(plan, K, 4)) : streamCvtServes(plan->fmt[0], K)))
         return BSMR_ERR_BAD_PLAN;
     BSMR_HIP(hipSetDevice(plan->device));
     const uint64_t key = ((uint64_t)K << 8) | (uint32_t)mode;

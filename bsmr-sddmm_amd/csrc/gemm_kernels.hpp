@@ -27,6 +27,11 @@
 //     and ordered by (row, column): 64 lanes read 256 contiguous bytes and write runs of P.  Entry words are read once per
 //     launch, i.e. from HBM: the first eight batches of a pass are requested one phase ahead (pass 0's in front of the last
 //     slice's MFMAs).
+//   * SRC32: the caller's fp32 operands, no conversion pass (K <= 128).  A stage then holds 32 k (rows of 128 bytes again:
+//     same DMA shape, K / 32 slices); a fragment is two ds_read_b128 (8 consecutive k as fp32) rounded in registers with the
+//     casts of convertOperands, so the MFMA operands - and P - are bit for bit those of conversion pass + 16-bit kernel.
+//     The XOR of the 16-byte pieces is another one (a lane's two pieces are neighbours; the 16 lanes a read is served in
+//     hold rows 0-3, 12-15 at pieces 2 g, 2 g + 1 and rows 4-11 at 2 g + 2, 2 g + 3): piece ^ swz32(row), below.
 // Measured (tools/probes/gemm_probe.hip, MI355X): 4096^2 Bernoulli(0.1), K = 512, bf16: the K loop runs at 1.5 us per slice
 // = 1.4 PFLOP/s executed, the rate of the guide's 256^2 8-phase GEMM template on random data; what is left is the fixed
 // part (launch, first stage, epilogue).
@@ -40,8 +45,11 @@
 
 namespace bsmr {
 
-constexpr uint32_t kGemmBK = 64;                                   // k per LDS stage
-constexpr uint32_t kGemmRowBytes = kGemmBK * 2u;                   // one row / column of a stage
+constexpr uint32_t kGemmBK = 64;                                   // k per LDS stage (16-bit operands; fp32 operands: 32)
+constexpr uint32_t kGemmRowBytes = kGemmBK * 2u;                   // one row / column of a stage: 128 bytes either way
+// the XOR that spreads a row's eight 16-byte pieces over the LDS banks, 16-bit and fp32 stages
+__host__ __device__ constexpr uint32_t gemmSwz16(uint32_t row) { return (row >> 1) & 7u; }
+__host__ __device__ constexpr uint32_t gemmSwz32(uint32_t row) { return ((row >> 1) & 1u) | (((row >> 3) & 1u) * 6u); }
 constexpr uint32_t gemmStageBytes(int PM, int NB) { return (uint32_t)(PM + NB) * 16u * kGemmRowBytes; }
 constexpr uint32_t kGemmSlabBytes = kGemmPassTiles * 1024u;         // a wave's slab: 16 tiles of 64 lanes x 16 bytes
 // two stages, reused as the eight waves' slabs by the epilogue
@@ -49,7 +57,6 @@ constexpr uint32_t gemmRingBytes(int PM, int NB) {
     return 2u * gemmStageBytes(PM, NB) > kGemmWaves * kGemmSlabBytes ? 2u * gemmStageBytes(PM, NB) : kGemmWaves * kGemmSlabBytes;
 }
 constexpr size_t gemmLdsBytes(int PM, int NB) { return gemmRingBytes(PM, NB) + (size_t)PM * 16u * 4u; }
-constexpr uint32_t kGemmWordChunk = 8;                             // batches of 64 entry words requested together
 
 #if defined(BSMR_GEMM_LAB)
 #define GEMM_LAB_ARG , uint32_t labSkip   /* bit 0 MFMAs, 1 fragment reads, 2 DMAs, 3 slab writes, 4 entry loads, 5 stores */
@@ -72,10 +79,10 @@ __device__ __forceinline__ void gemmKeep(const u32x4& x) {
 // byte offset of its piece in slice 0, kOff = the slice's byte offset inside a row.  (A function of its own: a buffer
 // resource cannot be captured by a lambda of a kernel that the host pass instantiates too.)
 template <uint32_t ADMAS, uint32_t BDMAS>
-__device__ __forceinline__ void gemmStage(const uint16_t* A, uint32_t aBytes, const uint16_t* B, uint32_t bBytes, uint8_t* stage, uint32_t bAt,
+__device__ __forceinline__ void gemmStage(const uint8_t* A, uint32_t aBytes, const uint8_t* B, uint32_t bBytes, uint8_t* stage, uint32_t bAt,
                                           uint32_t wave, const uint32_t* voffA, const uint32_t* voffB, uint32_t kOff) {
-    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A), 0, aBytes, 0x00020000);
-    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(B), 0, bBytes, 0x00020000);
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, aBytes, 0x00020000);
+    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(B), 0, bBytes, 0x00020000);
 #pragma unroll
     for (uint32_t j = 0; j < BDMAS; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (__attribute__((address_space(3))) void*)(stage + bAt + (wave * BDMAS + j) * 1024u), 16,
@@ -88,18 +95,22 @@ __device__ __forceinline__ void gemmStage(const uint16_t* A, uint32_t aBytes, co
 
 // grid: numItems x batches.  gridG / gridS: row groups / column strips of the format; fullGrid != 0: every macro-tile is an
 // item and item i's place follows from i alone (gemmItemPlace), so nothing waits for the item record.
-template <int KT, int PM, int NB, int MODE>
+// KT: slices of K (64 k each on 16-bit operands, 32 k each on fp32 operands).
+template <int KT, int PM, int NB, int MODE, bool SRC32 = false>
 __global__ void __launch_bounds__(kGemmWaves * kWave, 2)
-denseGemm(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, uint32_t aBytes, uint32_t bBytes,
+denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t aBytes, uint32_t bBytes,
           const uint32_t* __restrict__ panelRows, const GemmItem* __restrict__ items, const uint32_t* __restrict__ rowStart,
           const uint32_t* __restrict__ lists, const uint32_t* __restrict__ words, float* __restrict__ P, uint32_t N,
           uint32_t gridG, uint32_t gridS, uint32_t fullGrid, Batch batch GEMM_LAB_ARG) {
-    constexpr uint32_t K = kGemmBK * KT, TM = PM * 16u, TN = NB * 16u;
+    constexpr uint32_t ESZ = SRC32 ? 4u : 2u, K = (kGemmRowBytes / ESZ) * KT, TM = PM * 16u, TN = NB * 16u;
+    constexpr uint32_t KSUB = SRC32 ? 1u : 2u;                                  // 32-k MFMA steps per slice
     constexpr uint32_t m = PM / kGemmWavesM, n = NB / kGemmWavesN, Q = (m * n + kGemmPassTiles - 1u) / kGemmPassTiles, L = kGemmWaves * Q;
     constexpr uint32_t ADMAS = PM / 4u, BDMAS = NB / 4u;                        // LDS-DMA instructions per wave and slice
     static_assert(PM % 4 == 0 && NB % 4 == 0, "a stage is filled in whole 1-KiB pieces per wave");
     constexpr uint32_t stageBytes = gemmStageBytes(PM, NB), bAt = TM * kGemmRowBytes;
     constexpr uint32_t rowTableAt = gemmRingBytes(PM, NB);
+    // batches of 64 entry words requested together (fewer where the accumulators leave few registers)
+    constexpr uint32_t kGemmWordChunk = m * n > 32u ? 4u : 8u;
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t itemId = xcdContiguous(blockIdx.x, gridDim.x);
@@ -118,24 +129,24 @@ denseGemm(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, ui
     const uint32_t wm = wave / kGemmWavesN, wn = wave % kGemmWavesN;
     const uint32_t r = lane & 15u, g = lane >> 4;
 
-    const uint16_t* Ab = A16 + (size_t)blockIdx.y * batch.strideA;
-    const uint16_t* Bb = B16 + (size_t)blockIdx.y * batch.strideB;
+    const uint8_t* Ab = static_cast<const uint8_t*>(Aop) + (size_t)blockIdx.y * batch.strideA * ESZ;
+    const uint8_t* Bb = static_cast<const uint8_t*>(Bop) + (size_t)blockIdx.y * batch.strideB * ESZ;
     P += (size_t)blockIdx.y * batch.strideP;
 
     // my pieces of a stage: DMA instruction i = wave * DMAS + j moves rows 8 i .. 8 i + 7, lane l the 16-byte slot l & 7 of
-    // row 8 i + (l >> 3); the piece that belongs in that slot is slot ^ ((row >> 1) & 7)
+    // row 8 i + (l >> 3); the piece that belongs in that slot is slot ^ swz(row)
     uint32_t voffA[ADMAS], voffB[BDMAS];
 #pragma unroll
     for (uint32_t j = 0; j < ADMAS; ++j) {
         const uint32_t row = 8u * (wave * ADMAS + j) + (lane >> 3);
         const uint32_t id = panelRows[(size_t)group * TM + row];
-        voffA[j] = id * (K * 2u) + (((lane & 7u) ^ ((row >> 1) & 7u)) << 4);
+        voffA[j] = id * (K * ESZ) + (((lane & 7u) ^ (SRC32 ? gemmSwz32(row) : gemmSwz16(row))) << 4);
     }
 #pragma unroll
     for (uint32_t j = 0; j < BDMAS; ++j) {
         const uint32_t col = 8u * (wave * BDMAS + j) + (lane >> 3);
         const uint32_t id = min(firstBlock * 16u + col, N - 1u);                 // the last block of B may be ragged
-        voffB[j] = id * (K * 2u) + (((lane & 7u) ^ ((col >> 1) & 7u)) << 4);
+        voffB[j] = id * (K * ESZ) + (((lane & 7u) ^ (SRC32 ? gemmSwz32(col) : gemmSwz16(col))) << 4);
     }
     if (!GEMM_LAB_SKIP(2)) gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds, bAt, wave, voffA, voffB, 0u);
     // the macro-tile's table of first indices, one row per thread
@@ -145,8 +156,9 @@ denseGemm(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, ui
 #pragma unroll
     for (uint32_t q = 0; q <= Q; ++q) myList[q] = lists[listBase + wave * Q + q];
 
-    // fragment addresses: row / column r of a tile, k-group g; piece 4 s + g of the 128-byte row sits at slot (4 s + g) ^ (r >> 1)
-    const uint32_t fragOff = r * kGemmRowBytes + ((g ^ (r >> 1)) << 4);        // s = 0; s = 1 is this ^ 64
+    // fragment addresses: row / column r of a tile, k-group g.  16-bit: piece 4 s + g of the 128-byte row sits at slot
+    // (4 s + g) ^ (r >> 1) (s = 1 is s = 0's address ^ 64).  fp32: pieces 2 g and 2 g + 1 at (2 g) ^ swz32(r) and that ^ 1.
+    const uint32_t fragOff = r * kGemmRowBytes + ((SRC32 ? (2u * g) ^ gemmSwz32(r) : g ^ gemmSwz16(r)) << 4);
     const uint32_t aRead = wm * (TM / 2u) * kGemmRowBytes + fragOff;
     const uint32_t bRead = bAt + wn * (TN / 4u) * kGemmRowBytes + fragOff;
 
@@ -173,20 +185,25 @@ denseGemm(const uint16_t* __restrict__ A16, const uint16_t* __restrict__ B16, ui
         if (t + 1u == (uint32_t)KT) loadWords(myList[0], wNext);   // pass 0's first words: an HBM round trip, hidden behind the last slice
         const uint8_t* base = lds + (t & 1u) * stageBytes;
 #pragma unroll
-        for (uint32_t s = 0; s < 2; ++s) {
+        for (uint32_t s = 0; s < KSUB; ++s) {
+            // fragment of row / column tile `tile` at base address `at`: 16-bit operands as they lie; fp32 operands rounded here
+            auto fragment = [&](uint32_t at, uint32_t tile, uint32_t tag) -> u32x4 {
+                if (GEMM_LAB_SKIP(1)) return u32x4{lane, t, tile, s + tag};
+                const uint8_t* src = base + ((at + tile * 16u * kGemmRowBytes) ^ (s << 6));
+                if constexpr (SRC32) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(src) ^ 16u));
+                    return packLowp<MODE>(lo, hi);
+                } else {
+                    return *reinterpret_cast<const u32x4*>(src);
+                }
+            };
             u32x4 bf[n];
-            if (!GEMM_LAB_SKIP(1)) {
 #pragma unroll
-                for (uint32_t j = 0; j < n; ++j) bf[j] = *reinterpret_cast<const u32x4*>(base + ((bRead + j * 16u * kGemmRowBytes) ^ (s << 6)));
-            } else {
-#pragma unroll
-                for (uint32_t j = 0; j < n; ++j) bf[j] = u32x4{lane, t, j, s};
-            }
+            for (uint32_t j = 0; j < n; ++j) bf[j] = fragment(bRead, j, 0u);
 #pragma unroll
             for (uint32_t i = 0; i < m; ++i) {
-                u32x4 af;
-                if (!GEMM_LAB_SKIP(1)) af = *reinterpret_cast<const u32x4*>(base + ((aRead + i * 16u * kGemmRowBytes) ^ (s << 6)));
-                else af = u32x4{lane, t, i, s + 2u};
+                const u32x4 af = fragment(aRead, i, 2u);
                 if (!GEMM_LAB_SKIP(0)) {
 #pragma unroll
                     for (uint32_t j = 0; j < n; ++j) acc[i][j] = mfma16<MODE>(af, bf[j], acc[i][j]);

@@ -55,7 +55,7 @@ class TuneReport(C.Structure):
                 ("chosen_cvt_in_kernel", C.c_int32), ("convert_pass_us", C.c_float), ("fp32_dense_us", C.c_float),
                 ("sweep_us", C.c_float), ("lowp_call_us", C.c_float), ("sweep_fp32_call_us", C.c_float),
                 ("chosen_sweep_fp32", C.c_int32), ("chosen_variant", C.c_int32), ("variant_us", C.c_float * 6),
-                ("gemm_us", C.c_float)]
+                ("gemm_us", C.c_float), ("gemm_fp32_call_us", C.c_float), ("chosen_gemm_fp32", C.c_int32)]
 
 
 class TunedChoice(C.Structure):
@@ -88,7 +88,7 @@ class PlanOptions(C.Structure):
         "column_order", "dense_stream", "dense_batch", "tile_group", "tile_blocks_per_item", "tile_depth",
         "sparse_entries_per_item", "sparse_lowp", "sparse_lpe", "free_residue", "convert_in_kernel", "convert_sliced",
         "b_only", "b_only_work_m", "overlap_streams", "mask_tiles", "pack_on_device", "sweep_panels", "sweep_strip_blocks",
-        "sweep_fp32", "sweep_waves", "sweep_per_cu", "k_hint", "promote_on_device", "gemm_panels", "gemm_blocks")]
+        "sweep_fp32", "sweep_waves", "sweep_per_cu", "k_hint", "promote_on_device", "gemm_panels", "gemm_blocks", "gemm_fp32")]
 
 
 ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED, ENGINE_TUNED, ENGINE_SWEEP, ENGINE_GEMM = 0, 1, 2, 3, 4, 5
@@ -527,10 +527,11 @@ def plan_tune(plan, K: int, A_ptr: int, B_ptr: int, P_ptr: int, mode=COMPUTE_F16
     r = TuneReport()
     _check(hip().bsmr_plan_tune(plan, K, A_ptr, B_ptr, P_ptr, mode, stream, C.byref(r)), "bsmr_plan_tune")
     out = {"chosen": ENGINE_NAMES[r.chosen_engine], "group": r.chosen_group, "blocks_per_item": r.chosen_blocks_per_item}
-    for name in ("stream_us", "grouped_us", "tiles_us", "shared_us", "fp32_residue_us", "b_only_us", "one_stream_us", "two_streams_us", "convert_pass_us", "fp32_dense_us", "sweep_us", "lowp_call_us", "sweep_fp32_call_us", "gemm_us"):
+    for name in ("stream_us", "grouped_us", "tiles_us", "shared_us", "fp32_residue_us", "b_only_us", "one_stream_us", "two_streams_us", "convert_pass_us", "fp32_dense_us", "sweep_us", "lowp_call_us", "sweep_fp32_call_us", "gemm_us", "gemm_fp32_call_us"):
         out[name] = round(getattr(r, name), 2)
     out["b_only"], out["overlap"], out["cvt_in_kernel"] = r.chosen_b_only, r.chosen_overlap, r.chosen_cvt_in_kernel
     out["sweep_fp32"] = r.chosen_sweep_fp32
+    out["gemm_fp32"] = r.chosen_gemm_fp32
     out["variant"] = VARIANT_NAMES[r.chosen_variant]
     out["variant_us"] = {VARIANT_NAMES[i]: round(r.variant_us[i], 2) for i in range(6) if r.variant_us[i] >= 0}
     return out

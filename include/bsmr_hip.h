@@ -217,6 +217,9 @@ typedef struct bsmr_plan_options {
                                        8, 16                                                                   [GEMM_PANELS] */
     int32_t  gemm_blocks;           /* 16-column blocks of B per macro-tile: 0 = from the plan's shape; 12, 16, 20 (with 16
                                        panels), 16, 20 (with 8)                                                 [GEMM_BLOCKS] */
+    int32_t  gemm_fp32;             /* GEMM kernel on the caller's fp32 operands, rounded in registers (K = 64, 128; no
+                                       conversion pass; a residue then runs its fp32 kernel): -1 = when the plan has no
+                                       residue (default), 0 = never, 1 = whenever K allows                        [GEMM_FP32] */
 } bsmr_plan_options;
 int bsmr_plan_options_default(bsmr_plan_options *opt);
 /* defaults, then every BSMR_<NAME> variable that is set */
@@ -277,6 +280,10 @@ typedef struct bsmr_tune_report {
     /* GEMM engine (round 4; appended): best dense-kernel time on 16-bit operands over the macro-tile shapes tried; when it is
      * chosen, chosen_group = panels and chosen_blocks_per_item = 16-column blocks per macro-tile */
     float   gemm_us;
+    /* K = 64 / 128, whole calls: the GEMM kernel on the caller's fp32 operands (no conversion pass) against the best of the
+     * rest (lowp_call_us, or sweep_fp32_call_us where that had won) */
+    float   gemm_fp32_call_us;
+    int32_t chosen_gemm_fp32;         /* 1: the chosen engine is the GEMM kernel on fp32 operands */
 } bsmr_tune_report;
 #define BSMR_VARIANT_RULES        0   /* the options the plan was created with                                    */
 #define BSMR_VARIANT_AS_RPHM      1   /* the RPHM's split as it is: nothing promoted, nothing folded              */

@@ -40,6 +40,8 @@ def test_gemm_engine_matches_the_oracle(engine, oracle, monkeypatch, K, mode):
     for panels, blocks in SHAPES + [(0, 0)]:
         monkeypatch.setenv("BSMR_GEMM_PANELS", str(panels))
         monkeypatch.setenv("BSMR_GEMM_BLOCKS", str(blocks))
+        # (K = 64 / 128 on an all-dense plan: by default the kernel on the caller's fp32 operands; every second shape the 16-bit copies)
+        monkeypatch.setenv("BSMR_GEMM_FP32", "0" if (panels + blocks) % 8 else "-1")
         pipe = check_case(engine, oracle, rows, cols, ro, ci, K, 0.3, 0.0, mode)
         assert pipe.dense_choice(K)["group_size"] in (8, 16)        # the engine ran (panels per macro-tile)
         check_case(engine, oracle, rows, cols, ro, ci, K, 0.3, 0.1, mode)      # hybrid: the residue kernel reads the 16-bit copies too
@@ -70,9 +72,22 @@ def test_gemm_engine_is_bit_identical_to_the_streaming_engine(engine, K, mode):
         for panels, blocks in SHAPES:
             got, (group, tiles) = _run(engine, rows, cols, csr.nnz, arrays, K, A, B, mode,
                                        engine.plan_options(fold_dense_below=0, dense_engine=engine.ENGINE_GEMM, gemm_panels=panels,
-                                                           gemm_blocks=blocks))
+                                                           gemm_blocks=blocks, gemm_fp32=0))
             assert group == panels and tiles % (panels * blocks) == 0
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (delta, panels, blocks)
+            if K <= 128 and blocks != 12:
+                # the caller's fp32 operands rounded in the kernel (no conversion pass): the same MFMA operands; the residue
+                # of such a call runs its fp32 kernel, so only the dense entries are compared on the hybrid plan
+                got, (group, tiles) = _run(engine, rows, cols, csr.nnz, arrays, K, A, B, mode,
+                                           engine.plan_options(fold_dense_below=0, dense_engine=engine.ENGINE_GEMM, gemm_panels=panels,
+                                                               gemm_blocks=blocks, gemm_fp32=1, sparse_lowp=0))
+                assert group == panels and not np.isnan(got).any()
+                dense = np.ones(csr.nnz, dtype=bool)
+                if delta > 0:
+                    bv = pipe.array("blockValues")
+                    dense[:] = False
+                    dense[bv[bv != 0xFFFFFFFF]] = True
+                assert np.array_equal(got[dense].view(np.uint32), ref[dense].view(np.uint32)), (delta, panels, blocks, "fp32 operands")
 
 
 def test_gemm_engine_output_indexing_and_unsorted_rows(engine, monkeypatch):

@@ -27,26 +27,32 @@
 
 using bsmr::GemmItem;
 #ifdef BSMR_GEMM_LAB
-typedef void (*Kernel)(const uint16_t*, const uint16_t*, uint32_t, uint32_t, const uint32_t*, const GemmItem*, const uint32_t*,
+typedef void (*Kernel)(const void*, const void*, uint32_t, uint32_t, const uint32_t*, const GemmItem*, const uint32_t*,
                        const uint32_t*, const uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, bsmr::Batch, uint32_t);
 #define LAB_ARGS , skip
 #else
-typedef void (*Kernel)(const uint16_t*, const uint16_t*, uint32_t, uint32_t, const uint32_t*, const GemmItem*, const uint32_t*,
+typedef void (*Kernel)(const void*, const void*, uint32_t, uint32_t, const uint32_t*, const GemmItem*, const uint32_t*,
                        const uint32_t*, const uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, bsmr::Batch);
 #define LAB_ARGS
 #endif
 struct Variant {
     const char* name;
     int KT, PM, NB, mode;
+    bool src32;
     Kernel kernel;
 };
-#define V(name, KT, PM, NB, MODE) {name, KT, PM, NB, MODE, bsmr::denseGemm<KT, PM, NB, MODE>}
+#define V(name, KT, PM, NB, MODE) {name, KT, PM, NB, MODE, false, bsmr::denseGemm<KT, PM, NB, MODE, false>}
+#define V32(name, KT, PM, NB, MODE) {name, KT, PM, NB, MODE, true, bsmr::denseGemm<KT, PM, NB, MODE, true>}
 static const Variant kVariants[] = {
     V("k512_b_256x256", 8, 16, 16, 1), V("k512_b_128x256", 8, 8, 16, 1), V("k512_b_256x128", 8, 16, 8, 1),
     V("k512_b_256x320", 8, 16, 20, 1), V("k512_b_256x192", 8, 16, 12, 1), V("k512_b_128x320", 8, 8, 20, 1),
     V("k256_h_256x256", 4, 16, 16, 0), V("k128_h_256x256", 2, 16, 16, 0), V("k128_h_128x256", 2, 8, 16, 0),
     V("k128_h_256x128", 2, 16, 8, 0), V("k128_h_256x320", 2, 16, 20, 0), V("k128_h_256x192", 2, 16, 12, 0),
     V("k64_h_256x256", 1, 16, 16, 0),
+    // fp32 operands, rounded in the kernel (KT = K / 32)
+    V32("k128_f32_256x256", 4, 16, 16, 0), V32("k128_f32_256x320", 4, 16, 20, 0), V32("k128_f32_128x256", 4, 8, 16, 0),
+    V32("k128_f32_128x320", 4, 8, 20, 0), V32("k64_f32_256x256", 2, 16, 16, 0), V32("k32_f32_256x256", 1, 16, 16, 0),
+    V32("k128_f32b_256x320", 4, 16, 20, 1),
 };
 
 static uint16_t toF16(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
@@ -73,7 +79,7 @@ int main(int argc, char** argv) {
     const int iters = argc > 5 ? atoi(argv[5]) : 200;
     const uint32_t skip = argc > 6 ? (uint32_t)strtoul(argv[6], nullptr, 0) : 0u;
     (void)skip;
-    const uint32_t K = 64u * v->KT;
+    const uint32_t K = (v->src32 ? 32u : 64u) * v->KT;
 
     // pattern: i.i.d. Bernoulli(density), CSR with sorted rows; panels in natural row order
     std::mt19937 rng(4);
@@ -114,19 +120,21 @@ int main(int argc, char** argv) {
     std::vector<float> Af(A16.size()), Bf(B16.size());
     std::mt19937 gen(5489);
     auto draw = [&]() { return 2.0f * (float)(gen() >> 8) * (1.0f / 16777216.0f); };
-    for (size_t i = 0; i < A16.size(); ++i) { const float x = draw(); A16[i] = v->mode ? toBf16(x) : toF16(x); Af[i] = v->mode ? fromBf16(A16[i]) : fromF16(A16[i]); }
-    for (size_t i = 0; i < B16.size(); ++i) { const float x = draw(); B16[i] = v->mode ? toBf16(x) : toF16(x); Bf[i] = v->mode ? fromBf16(B16[i]) : fromF16(B16[i]); }
+    std::vector<float> A32(v->src32 ? A16.size() : 0), B32(v->src32 ? B16.size() : 0);   // what the fp32 kernel reads
+    for (size_t i = 0; i < A16.size(); ++i) { const float x = draw(); if (v->src32) A32[i] = x; A16[i] = v->mode ? toBf16(x) : toF16(x); Af[i] = v->mode ? fromBf16(A16[i]) : fromF16(A16[i]); }
+    for (size_t i = 0; i < B16.size(); ++i) { const float x = draw(); if (v->src32) B32[i] = x; B16[i] = v->mode ? toBf16(x) : toF16(x); Bf[i] = v->mode ? fromBf16(B16[i]) : fromF16(B16[i]); }
 
-    uint16_t *dA, *dB;
+    uint8_t *dA, *dB;
+    const size_t esz = v->src32 ? 4 : 2;
     uint32_t *dRows, *dRowStart, *dLists, *dWords;
     GemmItem* dItems;
     float* dP;
-    CHECK(hipMalloc(&dA, A16.size() * 2)); CHECK(hipMalloc(&dB, B16.size() * 2));
+    CHECK(hipMalloc(&dA, A16.size() * esz)); CHECK(hipMalloc(&dB, B16.size() * esz));
     CHECK(hipMalloc(&dRows, f.panelRows.size() * 4)); CHECK(hipMalloc(&dItems, f.items.size() * sizeof(GemmItem)));
     CHECK(hipMalloc(&dRowStart, f.rowStart.size() * 4)); CHECK(hipMalloc(&dLists, f.lists.size() * 4));
     CHECK(hipMalloc(&dWords, f.words.size() * 4)); CHECK(hipMalloc(&dP, (size_t)nnz * 4));
-    CHECK(hipMemcpy(dA, A16.data(), A16.size() * 2, hipMemcpyHostToDevice));
-    CHECK(hipMemcpy(dB, B16.data(), B16.size() * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dA, v->src32 ? (const void*)A32.data() : (const void*)A16.data(), A16.size() * esz, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dB, v->src32 ? (const void*)B32.data() : (const void*)B16.data(), B16.size() * esz, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(dRows, f.panelRows.data(), f.panelRows.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(dItems, f.items.data(), f.items.size() * sizeof(GemmItem), hipMemcpyHostToDevice));
     CHECK(hipMemcpy(dRowStart, f.rowStart.data(), f.rowStart.size() * 4, hipMemcpyHostToDevice));
@@ -139,8 +147,8 @@ int main(int argc, char** argv) {
     const bsmr::Batch batch{0, 0, 0, 1};
     const uint32_t full = f.fullGrid && !getenv("GEMM_ITEMS") ? 1u : 0u;   // GEMM_ITEMS=1: take the places from the item records
     auto launch = [&]() {
-        hipLaunchKernelGGL(v->kernel, dim3((uint32_t)f.items.size()), dim3(512), lds, nullptr, dA, dB, (uint32_t)(A16.size() * 2),
-                           (uint32_t)(B16.size() * 2), dRows, dItems, dRowStart, dLists, dWords, dP, N, f.numGroups, f.numStrips, full, batch LAB_ARGS);
+        hipLaunchKernelGGL(v->kernel, dim3((uint32_t)f.items.size()), dim3(512), lds, nullptr, dA, dB, (uint32_t)(A16.size() * esz),
+                           (uint32_t)(B16.size() * esz), dRows, dItems, dRowStart, dLists, dWords, dP, N, f.numGroups, f.numStrips, full, batch LAB_ARGS);
     };
     launch();
     CHECK(hipGetLastError());
