@@ -1313,15 +1313,26 @@ int ensureGemm(bsmr_plan* p, uint32_t K) {
     }
 }
 
+// SRC32: the caller's fp32 operands, every element rounded once per macro-tile through a second LDS image (denseGemmCvt);
+// otherwise the 16-bit copies (denseGemm)
 template <int KT, int PM, int NB, int MODE, bool SRC32>
 int launchGemmT(const GemmFormatDev& w, const bsmr_plan* p, const void* A, const void* B, float* P, const Queue& s) {
-    auto kernel = bsmr::denseGemm<KT, PM, NB, MODE, SRC32>;
-    const size_t lds = bsmr::gemmLdsBytes(PM, NB);
-    if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, p->device)) return st;
     const uint64_t K = (SRC32 ? 32u : 64u) * KT, esz = SRC32 ? 4 : 2;
-    hipLaunchKernelGGL(kernel, dim3(w.numItems, s.batch.count), dim3(bsmr::kGemmWaves * bsmr::kWave), lds, s, A, B,
-                       (uint32_t)((uint64_t)p->M * K * esz), (uint32_t)((uint64_t)p->N * K * esz), w.panelRows, w.items, w.rowStart, w.lists,
-                       w.words, P, p->N, w.numGroups, w.numStrips, w.fullGrid ? 1u : 0u, s.batch);
+    const uint32_t aBytes = (uint32_t)((uint64_t)p->M * K * esz), bBytes = (uint32_t)((uint64_t)p->N * K * esz);
+    const dim3 grid(w.numItems, s.batch.count), block(bsmr::kGemmWaves * bsmr::kWave);
+    if constexpr (SRC32) {
+        auto kernel = bsmr::denseGemmCvt<KT, PM, NB, MODE>;
+        const size_t lds = bsmr::gemmCvtLdsBytes(PM, NB);
+        if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, p->device)) return st;
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, static_cast<const float*>(A), static_cast<const float*>(B), aBytes, bBytes, w.panelRows,
+                           w.items, w.rowStart, w.lists, w.words, P, p->N, w.numGroups, w.numStrips, w.fullGrid ? 1u : 0u, s.batch);
+    } else {
+        auto kernel = bsmr::denseGemm<KT, PM, NB, MODE, false>;
+        const size_t lds = bsmr::gemmLdsBytes(PM, NB);
+        if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, p->device)) return st;
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, A, B, aBytes, bBytes, w.panelRows, w.items, w.rowStart, w.lists, w.words, P, p->N,
+                           w.numGroups, w.numStrips, w.fullGrid ? 1u : 0u, s.batch);
+    }
     BSMR_HIP(hipGetLastError());
     return BSMR_OK;
 }
@@ -1748,6 +1759,8 @@ const char* bsmr_strerror(int status) {
 }
 
 const char* bsmr_last_hip_error(void) { return g_lastHipError.c_str(); }
+
+int bsmr_abi_revision(void) { return BSMR_ABI_REVISION; }
 
 int bsmr_device_count(int* count) {
     if (!count) return BSMR_ERR_INVALID_ARG;

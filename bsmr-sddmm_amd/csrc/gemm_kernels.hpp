@@ -59,7 +59,7 @@ constexpr uint32_t gemmRingBytes(int PM, int NB) {
 constexpr size_t gemmLdsBytes(int PM, int NB) { return gemmRingBytes(PM, NB) + (size_t)PM * 16u * 4u; }
 
 #if defined(BSMR_GEMM_LAB)
-#define GEMM_LAB_ARG , uint32_t labSkip   /* bit 0 MFMAs, 1 fragment reads, 2 DMAs, 3 slab writes, 4 entry loads, 5 stores */
+#define GEMM_LAB_ARG , uint32_t labSkip   /* bit 0 MFMAs, 1 fragment reads (denseGemmCvt: the rounding step), 2 DMAs, 3 slab writes, 4 entry loads, 5 stores, 6 denseGemmCvt's fragment reads */
 #define GEMM_LAB_SKIP(bit) (labSkip & (1u << (bit)))
 #else
 #define GEMM_LAB_ARG
@@ -238,6 +238,201 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
         if (q + 1u < Q) loadWords(last, wNext);                     // the next pass's first words (lists follow each other)
         for (uint32_t e = first; e < last; e += kGemmWordChunk * kWave) {
             if (e != first) loadWords(e, w);                         // (a list of more than 512 words: rare)
+#pragma unroll
+            for (uint32_t u = 0; u < kGemmWordChunk; ++u) {
+                if (e + u * kWave + lane < last && w[u] != kGemmNoEntry) {
+                    const float val = slab[w[u] & 4095u];
+                    const uint32_t dst = rowTable[(w[u] >> 12) & 127u] + (w[u] >> 19);
+                    if (!GEMM_LAB_SKIP(5)) P[dst] = val;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same macro-tile kernel on the caller's fp32 operands with ONE shared rounding per element (K = 64, 128).
+//
+// denseGemm<..., SRC32> lets every wave round the fragments it reads: the four waves of a row half round the same rows of A,
+// the two waves of a column quarter the same columns of B - 2.9 times the casts the operands need, all of them in front of
+// the MFMAs of an in-order wave (measured, nips-like K = 128: 13.4 us against 9.1 us for the kernel on 16-bit copies).  Here
+// a slice of 32 k goes through two LDS images:
+//   F  (TM + TN) rows x 128 bytes of fp32, filled by LDS-DMA, lane-linear (piece = slot: nothing reads it by fragment).  A
+//      wave's share of F is PRIVATE to it: the wave that issued the DMAs of a 1-KiB chunk is the one that rounds it, so
+//      its own counted wait orders everything and no barrier guards F;
+//   H  two stages of (TM + TN) rows x 64 bytes of fp16 / bf16 (rows of 32 k), written by the rounding step - 64 lanes read
+//      1 KiB of F linearly, round with the casts of convertOperands, write 8 bytes each - and read as MFMA fragments
+//      (ds_read_b128 of piece g of row r at slot g ^ swzH(r): conflict-free for the 16-lane groups a read is served in,
+//      as are the 8-byte writes).
+// Per slice: MFMAs of slice t from H[t & 1]; wait for the own DMAs of slice t + 1, round them into H[(t + 1) & 1], re-issue
+// the DMAs of slice t + 2 into the same chunks of F, ONE barrier (publishes H[(t + 1) & 1]; everybody's reads of it, two
+// slices ago, ended before the barrier in between).  Same casts, same MFMA, same order of k steps: bit-identical to the
+// conversion pass + 16-bit kernels.
+constexpr uint32_t kGemmHalfRowBytes = 64u;                        // a row of an H stage: 32 k of 16 bits
+__host__ __device__ constexpr uint32_t gemmSwzH(uint32_t row) { return (4u - ((row >> 2) & 3u)) & 3u; }   // 0, 3, 2, 1
+constexpr uint32_t gemmCvtRingBytes(int PM, int NB) {
+    const uint32_t used = (uint32_t)(PM + NB) * 16u * (kGemmRowBytes + 2u * kGemmHalfRowBytes);
+    return used > kGemmWaves * kGemmSlabBytes ? used : kGemmWaves * kGemmSlabBytes;
+}
+constexpr size_t gemmCvtLdsBytes(int PM, int NB) { return gemmCvtRingBytes(PM, NB) + (size_t)PM * 16u * 4u; }
+
+template <int KT, int PM, int NB, int MODE>
+__global__ void __launch_bounds__(kGemmWaves * kWave, 2)
+denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint32_t aBytes, uint32_t bBytes,
+             const uint32_t* __restrict__ panelRows, const GemmItem* __restrict__ items, const uint32_t* __restrict__ rowStart,
+             const uint32_t* __restrict__ lists, const uint32_t* __restrict__ words, float* __restrict__ P, uint32_t N,
+             uint32_t gridG, uint32_t gridS, uint32_t fullGrid, Batch batch GEMM_LAB_ARG) {
+    constexpr uint32_t K = 32u * KT, TM = PM * 16u, TN = NB * 16u, ROWS = TM + TN;
+    constexpr uint32_t m = PM / kGemmWavesM, n = NB / kGemmWavesN, Q = (m * n + kGemmPassTiles - 1u) / kGemmPassTiles, L = kGemmWaves * Q;
+    constexpr uint32_t ADMAS = PM / 4u, BDMAS = NB / 4u, DMAS = ADMAS + BDMAS;   // 1-KiB chunks of F per wave: 8 rows each
+    constexpr uint32_t fBytes = ROWS * kGemmRowBytes, hBytes = ROWS * kGemmHalfRowBytes, bAtF = TM * kGemmRowBytes, bAtH = TM * kGemmHalfRowBytes;
+    constexpr uint32_t hAt = fBytes, rowTableAt = gemmCvtRingBytes(PM, NB);
+    constexpr uint32_t kGemmWordChunk = m * n > 32u ? 4u : 8u;
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t itemId = xcdContiguous(blockIdx.x, gridDim.x);
+    uint32_t group, firstBlock, listBase;
+    if (fullGrid) {
+        gemmItemPlace(itemId, gridG, gridS, group, firstBlock);
+        firstBlock *= (uint32_t)NB;
+        listBase = itemId * (L + 1u);
+    } else {
+        const GemmItem item = items[itemId];
+        group = item.group;
+        firstBlock = item.firstBlock;
+        listBase = item.listBase;
+    }
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t wm = wave / kGemmWavesN, wn = wave % kGemmWavesN;
+    const uint32_t r = lane & 15u, g = lane >> 4;
+    const uint8_t* Ab = reinterpret_cast<const uint8_t*>(Aop) + (size_t)blockIdx.y * batch.strideA * 4u;
+    const uint8_t* Bb = reinterpret_cast<const uint8_t*>(Bop) + (size_t)blockIdx.y * batch.strideB * 4u;
+    P += (size_t)blockIdx.y * batch.strideP;
+
+    // my chunks of F: chunk c = wave * DMAS + j holds rows 8 c .. 8 c + 7 (A's chunks first, then B's), lane l the piece l & 7
+    // (k = 4 (l & 7) .. + 3) of row 8 c + (l >> 3); where the rounded piece goes in H: row * 64 + 16 (slot) + 8 (half)
+    uint32_t voffA[ADMAS], voffB[BDMAS];
+    const uint32_t piece = lane & 7u;
+#pragma unroll
+    for (uint32_t j = 0; j < ADMAS; ++j) {
+        const uint32_t row = 8u * (wave * ADMAS + j) + (lane >> 3);
+        voffA[j] = panelRows[(size_t)group * TM + row] * (K * 4u) + (piece << 4);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < BDMAS; ++j) {
+        const uint32_t col = 8u * (wave * BDMAS + j) + (lane >> 3);
+        voffB[j] = min(firstBlock * 16u + col, N - 1u) * (K * 4u) + (piece << 4);   // the last block of B may be ragged
+    }
+    if (!GEMM_LAB_SKIP(2)) gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds, bAtF, wave, voffA, voffB, 0u);
+    if (threadIdx.x < TM) reinterpret_cast<uint32_t*>(lds + rowTableAt)[threadIdx.x] = rowStart[(size_t)itemId * TM + threadIdx.x];
+    uint32_t myList[Q + 1];
+#pragma unroll
+    for (uint32_t q = 0; q <= Q; ++q) myList[q] = lists[listBase + wave * Q + q];
+
+    // rounding step: my chunks of F -> stage `to` of H
+    auto roundChunks = [&](uint32_t to) {
+        uint8_t* H = lds + hAt + to * hBytes;
+#pragma unroll
+        for (uint32_t j = 0; j < DMAS; ++j) {
+            const bool isA = j < ADMAS;
+            const uint32_t chunk = isA ? wave * ADMAS + j : wave * BDMAS + (j - ADMAS);
+            const uint32_t row = 8u * chunk + (lane >> 3);                       // row of A's part / of B's part
+            const uint8_t* src = lds + (isA ? 0u : bAtF) + chunk * 1024u + lane * 16u;
+            uint8_t* dst = H + (isA ? 0u : bAtH) + row * kGemmHalfRowBytes + (((piece >> 1) ^ gemmSwzH(row)) << 4) + ((piece & 1u) << 3);
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            if (GEMM_LAB_SKIP(1)) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+            u32x2 h;
+            if constexpr (MODE == 0) {
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                f16x4 o;
+                o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+                h = __builtin_bit_cast(u32x2, o);
+            } else {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 o;
+                o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+                h = __builtin_bit_cast(u32x2, o);
+            }
+            *reinterpret_cast<u32x2*>(dst) = h;
+        }
+    };
+
+    // fragment addresses in an H stage: piece g of row / column r at slot g ^ swzH(r)
+    const uint32_t fragOff = r * kGemmHalfRowBytes + ((g ^ gemmSwzH(r)) << 4);
+    const uint32_t aRead = wm * (TM / 2u) * kGemmHalfRowBytes + fragOff;
+    const uint32_t bRead = bAtH + wn * (TN / 4u) * kGemmHalfRowBytes + fragOff;
+
+    f32x4 acc[m][n];
+#pragma unroll
+    for (uint32_t i = 0; i < m; ++i)
+#pragma unroll
+        for (uint32_t j = 0; j < n; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto loadWords = [&](uint32_t e0, uint32_t (&w)[kGemmWordChunk]) {
+#pragma unroll
+        for (uint32_t u = 0; u < kGemmWordChunk; ++u) w[u] = GEMM_LAB_SKIP(4) ? kGemmNoEntry : words[e0 + u * kWave + lane];
+    };
+    uint32_t wNext[kGemmWordChunk];
+
+    // slice 0: landed (my chunks), rounded into H[0], slice 1 requested, H[0] published
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    roundChunks(0u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (KT > 1 && !GEMM_LAB_SKIP(2)) gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds, bAtF, wave, voffA, voffB, kGemmRowBytes);
+    __builtin_amdgcn_s_barrier();
+
+#pragma unroll
+    for (uint32_t t = 0; t < (uint32_t)KT; ++t) {
+        if (t + 1u == (uint32_t)KT) loadWords(myList[0], wNext);   // pass 0's first words: an HBM round trip, hidden behind the last slice
+        const uint8_t* base = lds + hAt + (t & 1u) * hBytes;
+        u32x4 bf[n];
+#pragma unroll
+        for (uint32_t j = 0; j < n; ++j)
+            bf[j] = GEMM_LAB_SKIP(6) ? u32x4{lane, t, j, 0u} : *reinterpret_cast<const u32x4*>(base + bRead + j * 16u * kGemmHalfRowBytes);
+#pragma unroll
+        for (uint32_t i = 0; i < m; ++i) {
+            const u32x4 af = GEMM_LAB_SKIP(6) ? u32x4{lane, t, i, 2u} : *reinterpret_cast<const u32x4*>(base + aRead + i * 16u * kGemmHalfRowBytes);
+            if (!GEMM_LAB_SKIP(0)) {
+#pragma unroll
+                for (uint32_t j = 0; j < n; ++j) acc[i][j] = mfma16<MODE>(af, bf[j], acc[i][j]);
+            } else {
+                gemmKeep(af);
+#pragma unroll
+                for (uint32_t j = 0; j < n; ++j) gemmKeep(bf[j]);
+            }
+        }
+        if (t + 1u < (uint32_t)KT) {
+            // my chunks of slice t + 1 have landed: round them into the other stage of H, then F takes slice t + 2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            roundChunks((t + 1u) & 1u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t + 2u < (uint32_t)KT && !GEMM_LAB_SKIP(2))
+                gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds, bAtF, wave, voffA, voffB, (t + 2u) * kGemmRowBytes);
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- the sparse mask: slab passes over the wave's tiles (as denseGemm)
+    float* slab = reinterpret_cast<float*>(lds) + wave * (kGemmPassTiles * 256u);
+    const uint32_t* rowTable = reinterpret_cast<const uint32_t*>(lds + rowTableAt) + wm * (TM / 2u);
+#pragma unroll
+    for (uint32_t q = 0; q < Q; ++q) {
+        if (!GEMM_LAB_SKIP(3)) {
+#pragma unroll
+            for (uint32_t tp = 0; tp < kGemmPassTiles; ++tp) {
+                const uint32_t tIdx = q * kGemmPassTiles + tp;
+                if (tIdx < m * n) *reinterpret_cast<f32x4*>(slab + (tp * 64u + lane) * 4u) = acc[tIdx / n][tIdx % n];
+            }
+        }
+        const uint32_t first = myList[q], last = myList[q + 1u];
+        uint32_t w[kGemmWordChunk];
+#pragma unroll
+        for (uint32_t u = 0; u < kGemmWordChunk; ++u) w[u] = wNext[u];
+        if (q + 1u < Q) loadWords(last, wNext);
+        for (uint32_t e = first; e < last; e += kGemmWordChunk * kWave) {
+            if (e != first) loadWords(e, w);
 #pragma unroll
             for (uint32_t u = 0; u < kGemmWordChunk; ++u) {
                 if (e + u * kWave + lane < last && w[u] != kGemmNoEntry) {

@@ -61,11 +61,17 @@ struct bsmr_sharded {
     std::vector<int> uniqueDevices;      // the distinct devices, root first; rankOf[i] = index of devices[i] in it
     std::vector<int> rankOf;
     std::vector<ncclComm_t> comms;       // one per distinct device (single-process communicator clique), empty for one device
-    std::vector<hipStream_t> streams;
+    std::vector<hipStream_t> streams;    // compute stream of every shard
+    std::vector<hipStream_t> gatherStreams;   // the shard's part travels to the root on a stream of its own, behind an event
     std::vector<hipEvent_t> start, stop;
+    std::vector<hipEvent_t> computed[2], gathered[2], gatherStart;   // per shard and P buffer: SDDMM done / part delivered
     // device buffers of the last K served
     uint32_t K = 0;
-    std::vector<float*> A, B, P;         // P[0] holds the whole result (root), P[i>0] the shard's part
+    std::vector<float*> A, B;
+    // Two output buffers per shard, used by alternate steps: the gather of step i runs behind the SDDMM of step i + 1
+    // (the Python driver's PipelinedSteps, python/shard.py).  P[b][0] holds the whole result of a step (root), P[b][i > 0] the
+    // shard's part.
+    std::vector<float*> P[2];
 };
 
 namespace {
@@ -75,11 +81,13 @@ void freeShardedBuffers(bsmr_sharded* s) {
         if (hipSetDevice(s->devices[i]) != hipSuccess) (void)hipGetLastError();
         if (i < s->A.size() && s->A[i]) (void)hipFree(s->A[i]);
         if (i < s->B.size() && s->B[i]) (void)hipFree(s->B[i]);
-        if (i < s->P.size() && s->P[i]) (void)hipFree(s->P[i]);
+        for (auto& buf : s->P)
+            if (i < buf.size() && buf[i]) (void)hipFree(buf[i]);
     }
     s->A.clear();
     s->B.clear();
-    s->P.clear();
+    s->P[0].clear();
+    s->P[1].clear();
     s->K = 0;
 }
 
@@ -106,35 +114,49 @@ struct DeviceRestore {
     }
 };
 
-// the gather-v of one step: peers hand their part to the root, which receives each into its slot
-int shardedGather(bsmr_sharded* s) {
+// the gather-v of one step (output buffers `b`): peers hand their part to the root, which receives each into its slot.  All of
+// it runs on the gather streams, behind the event that says the shard's SDDMM of this step is done, so the compute streams
+// are free for the next step at once.
+int shardedGather(bsmr_sharded* s, int b) {
     const size_t n = s->devices.size();
     if (n == 1) return BSMR_OK;
-    // shards on the root's device: a device-to-device copy on the shard's own stream (behind its SDDMM)
+    for (size_t i = 0; i < n; ++i) {
+        BSMR_HIP(hipSetDevice(s->devices[i]));
+        BSMR_HIP(hipStreamWaitEvent(s->gatherStreams[i], s->computed[b][i], 0));
+        if (i == 0) {   // the root's receives also wait for nothing else: its own part was written in place
+            continue;
+        }
+    }
+    // shards on the root's device: a device-to-device copy
     for (size_t i = 1; i < n; ++i) {
         const uint64_t count = s->entryBegin[i + 1] - s->entryBegin[i];
         if (!count || s->rankOf[i] != 0) continue;
         BSMR_HIP(hipSetDevice(s->devices[i]));
-        BSMR_HIP(hipMemcpyAsync(s->P[0] + s->entryBegin[i], s->P[i], count * 4, hipMemcpyDeviceToDevice, s->streams[i]));
+        BSMR_HIP(hipMemcpyAsync(s->P[b][0] + s->entryBegin[i], s->P[b][i], count * 4, hipMemcpyDeviceToDevice, s->gatherStreams[i]));
     }
-    if (s->comms.empty()) return BSMR_OK;
-    // the rest crosses devices: one RCCL group; an error inside it still closes the group
     int status = BSMR_OK;
-    BSMR_NCCL(rccl().groupStart());
-    for (size_t i = 1; i < n && status == BSMR_OK; ++i) {
-        const uint64_t count = s->entryBegin[i + 1] - s->entryBegin[i];
-        if (!count || s->rankOf[i] == 0) continue;
-        ncclResult_t r = rccl().recv(s->P[0] + s->entryBegin[i], count, ncclFloat, s->rankOf[i], s->comms[0], s->streams[0]);
-        if (r == ncclSuccess) r = rccl().send(s->P[i], count, ncclFloat, 0, s->comms[(size_t)s->rankOf[i]], s->streams[i]);
-        if (r != ncclSuccess) {
-            g_lastHipError = std::string("ncclSend / ncclRecv: ") + rccl().errorString(r);
+    if (!s->comms.empty()) {
+        // the rest crosses devices: one RCCL group; an error inside it still closes the group
+        BSMR_NCCL(rccl().groupStart());
+        for (size_t i = 1; i < n && status == BSMR_OK; ++i) {
+            const uint64_t count = s->entryBegin[i + 1] - s->entryBegin[i];
+            if (!count || s->rankOf[i] == 0) continue;
+            ncclResult_t r = rccl().recv(s->P[b][0] + s->entryBegin[i], count, ncclFloat, s->rankOf[i], s->comms[0], s->gatherStreams[0]);
+            if (r == ncclSuccess) r = rccl().send(s->P[b][i], count, ncclFloat, 0, s->comms[(size_t)s->rankOf[i]], s->gatherStreams[i]);
+            if (r != ncclSuccess) {
+                g_lastHipError = std::string("ncclSend / ncclRecv: ") + rccl().errorString(r);
+                status = BSMR_ERR_HIP;
+            }
+        }
+        const ncclResult_t e = rccl().groupEnd();
+        if (e != ncclSuccess && status == BSMR_OK) {
+            g_lastHipError = std::string("ncclGroupEnd: ") + rccl().errorString(e);
             status = BSMR_ERR_HIP;
         }
     }
-    const ncclResult_t e = rccl().groupEnd();
-    if (e != ncclSuccess && status == BSMR_OK) {
-        g_lastHipError = std::string("ncclGroupEnd: ") + rccl().errorString(e);
-        status = BSMR_ERR_HIP;
+    for (size_t i = 0; i < n && status == BSMR_OK; ++i) {   // the buffer is free again once its part has been delivered
+        BSMR_HIP(hipSetDevice(s->devices[i]));
+        BSMR_HIP(hipEventRecord(s->gathered[b][i], s->gatherStreams[i]));
     }
     return status;
 }
@@ -154,8 +176,14 @@ int bsmr_sharded_destroy(bsmr_sharded* s) {
     for (size_t i = 0; i < s->devices.size(); ++i) {
         if (hipSetDevice(s->devices[i]) != hipSuccess) (void)hipGetLastError();
         if (i < s->streams.size() && s->streams[i]) (void)hipStreamDestroy(s->streams[i]);
+        if (i < s->gatherStreams.size() && s->gatherStreams[i]) (void)hipStreamDestroy(s->gatherStreams[i]);
         if (i < s->start.size() && s->start[i]) (void)hipEventDestroy(s->start[i]);
         if (i < s->stop.size() && s->stop[i]) (void)hipEventDestroy(s->stop[i]);
+        if (i < s->gatherStart.size() && s->gatherStart[i]) (void)hipEventDestroy(s->gatherStart[i]);
+        for (int b = 0; b < 2; ++b) {
+            if (i < s->computed[b].size() && s->computed[b][i]) (void)hipEventDestroy(s->computed[b][i]);
+            if (i < s->gathered[b].size() && s->gathered[b][i]) (void)hipEventDestroy(s->gathered[b][i]);
+        }
         if (i < s->plans.size() && s->plans[i]) bsmr_plan_destroy(s->plans[i]);
     }
     delete s;
@@ -188,8 +216,14 @@ int bsmr_sharded_create(bsmr_sharded** out, const int* devices, uint32_t num_dev
     s->entryBegin.assign(num_devices + 1, 0);
     s->plans.assign(num_devices, nullptr);
     s->streams.assign(num_devices, nullptr);
+    s->gatherStreams.assign(num_devices, nullptr);
     s->start.assign(num_devices, nullptr);
     s->stop.assign(num_devices, nullptr);
+    s->gatherStart.assign(num_devices, nullptr);
+    for (int b = 0; b < 2; ++b) {
+        s->computed[b].assign(num_devices, nullptr);
+        s->gathered[b].assign(num_devices, nullptr);
+    }
     int st = BSMR_OK;
     for (uint32_t i = 0; i < num_devices && st == BSMR_OK; ++i) {
         s->entryBegin[i + 1] = s->entryBegin[i] + shard_descs[i]->nnz;
@@ -202,7 +236,13 @@ int bsmr_sharded_create(bsmr_sharded** out, const int* devices, uint32_t num_dev
             break;
         }
         if (!hipOk(hipStreamCreateWithFlags(&s->streams[i], hipStreamNonBlocking), "hipStreamCreate") ||
-            !hipOk(hipEventCreate(&s->start[i]), "hipEventCreate") || !hipOk(hipEventCreate(&s->stop[i]), "hipEventCreate"))
+            !hipOk(hipStreamCreateWithFlags(&s->gatherStreams[i], hipStreamNonBlocking), "hipStreamCreate") ||
+            !hipOk(hipEventCreate(&s->start[i]), "hipEventCreate") || !hipOk(hipEventCreate(&s->stop[i]), "hipEventCreate") ||
+            !hipOk(hipEventCreate(&s->gatherStart[i]), "hipEventCreate") ||
+            !hipOk(hipEventCreateWithFlags(&s->computed[0][i], hipEventDisableTiming), "hipEventCreate") ||
+            !hipOk(hipEventCreateWithFlags(&s->computed[1][i], hipEventDisableTiming), "hipEventCreate") ||
+            !hipOk(hipEventCreateWithFlags(&s->gathered[0][i], hipEventDisableTiming), "hipEventCreate") ||
+            !hipOk(hipEventCreateWithFlags(&s->gathered[1][i], hipEventDisableTiming), "hipEventCreate"))
             st = BSMR_ERR_HIP;
     }
     if (st == BSMR_OK && s->uniqueDevices.size() > 1) {
@@ -242,23 +282,26 @@ int bsmr_sharded_sddmm_host(bsmr_sharded* s, uint32_t K, const float* A_host, co
     DeviceRestore restore;
     const size_t n = s->devices.size();
     const uint64_t nnz = s->entryBegin.back();
-    // operands: shard i's rows of A, all of B, its part of P (the root holds the whole P)
+    // operands: shard i's rows of A, all of B, its part of P twice (the root holds the whole P, twice)
     if (s->K != K) {
         freeShardedBuffers(s);
         s->A.assign(n, nullptr);
         s->B.assign(n, nullptr);
-        s->P.assign(n, nullptr);
+        s->P[0].assign(n, nullptr);
+        s->P[1].assign(n, nullptr);
         for (size_t i = 0; i < n; ++i) {
             BSMR_HIP(hipSetDevice(s->devices[i]));
             const size_t rows = s->rowBegin[i + 1] - s->rowBegin[i];
             const uint64_t part = i == 0 ? nnz : s->entryBegin[i + 1] - s->entryBegin[i];
             if (!hipOk(hipMalloc(reinterpret_cast<void**>(&s->A[i]), std::max<size_t>(rows * K * 4, 16)), "hipMalloc(A shard)") ||
                 !hipOk(hipMalloc(reinterpret_cast<void**>(&s->B[i]), std::max<size_t>((size_t)s->N * K * 4, 16)), "hipMalloc(B replica)") ||
-                !hipOk(hipMalloc(reinterpret_cast<void**>(&s->P[i]), std::max<size_t>(part * 4, 16)), "hipMalloc(P shard)"))
+                !hipOk(hipMalloc(reinterpret_cast<void**>(&s->P[0][i]), std::max<size_t>(part * 4, 16)), "hipMalloc(P shard)") ||
+                !hipOk(hipMalloc(reinterpret_cast<void**>(&s->P[1][i]), std::max<size_t>(part * 4, 16)), "hipMalloc(P shard)"))
                 return BSMR_ERR_OOM;
             // (every entry of P is written by exactly one shard's SDDMM or arrives with the gather: a byte pattern that reads
             // as NaN makes an entry that nobody wrote visible to the caller)
-            BSMR_HIP(hipMemsetAsync(s->P[i], 0xFF, std::max<size_t>(part * 4, 16), s->streams[i]));
+            BSMR_HIP(hipMemsetAsync(s->P[0][i], 0xFF, std::max<size_t>(part * 4, 16), s->streams[i]));
+            BSMR_HIP(hipMemsetAsync(s->P[1][i], 0xFF, std::max<size_t>(part * 4, 16), s->streams[i]));
             int st = s->plans[i] ? bsmr_plan_reserve(s->plans[i], K) : BSMR_OK;
             if (st != BSMR_OK) return st;
         }
@@ -270,37 +313,83 @@ int bsmr_sharded_sddmm_host(bsmr_sharded* s, uint32_t K, const float* A_host, co
         BSMR_HIP(hipMemcpyAsync(s->A[i], A_host + (size_t)(s->rowBegin[i] - s->rowBegin[0]) * K, rows * K * 4, hipMemcpyHostToDevice, s->streams[i]));
         BSMR_HIP(hipMemcpyAsync(s->B[i], B_host, (size_t)s->N * K * 4, hipMemcpyHostToDevice, s->streams[i]));
     }
-    for (size_t i = 0; i < n; ++i) {
-        BSMR_HIP(hipSetDevice(s->devices[i]));
-        BSMR_HIP(hipStreamSynchronize(s->streams[i]));
-    }
-    auto step = [&]() -> int {   // every device's SDDMM, then the gather
+    auto syncAll = [&]() -> int {
         for (size_t i = 0; i < n; ++i) {
             BSMR_HIP(hipSetDevice(s->devices[i]));
-            if (!s->plans[i]) continue;
-            float* dst = i == 0 ? s->P[0] + s->entryBegin[0] : s->P[i];
-            const int st = bsmr_sddmm(s->plans[i], K, s->A[i], s->B[i], dst, mode, s->streams[i]);
-            if (st != BSMR_OK) return st;
+            BSMR_HIP(hipStreamSynchronize(s->streams[i]));
+            BSMR_HIP(hipStreamSynchronize(s->gatherStreams[i]));
         }
-        return shardedGather(s);
+        return BSMR_OK;
     };
-    int st = step();   // warm-up (workspaces, communicator channels)
-    for (size_t i = 0; i < n && st == BSMR_OK; ++i) {
-        BSMR_HIP(hipSetDevice(s->devices[i]));
-        BSMR_HIP(hipStreamSynchronize(s->streams[i]));
-    }
+    if (int st = syncAll()) return st;
+    // one step into output buffers b: every device's SDDMM on its compute stream (which first waits until the gather that
+    // last read these buffers, two steps ago, has delivered), then the gather on the gather streams
+    auto step = [&](int b, bool waitForBuffer) -> int {
+        for (size_t i = 0; i < n; ++i) {
+            BSMR_HIP(hipSetDevice(s->devices[i]));
+            if (waitForBuffer) BSMR_HIP(hipStreamWaitEvent(s->streams[i], s->gathered[b][i], 0));
+            if (s->plans[i]) {
+                float* dst = i == 0 ? s->P[b][0] + s->entryBegin[0] : s->P[b][i];
+                const int st = bsmr_sddmm(s->plans[i], K, s->A[i], s->B[i], dst, mode, s->streams[i]);
+                if (st != BSMR_OK) return st;
+            }
+            BSMR_HIP(hipEventRecord(s->computed[b][i], s->streams[i]));
+        }
+        return shardedGather(s, b);
+    };
+    int st = step(0, false);   // warm-up (workspaces, communicator channels)
+    if (st == BSMR_OK) st = syncAll();
     if (st != BSMR_OK) return st;
+    // what the two halves of a step cost by themselves (one step each, nothing overlapped): SDDMM on every device, then the gather
+    float computeMs = 0.0f, gatherMs = 0.0f;
+    {
+        for (size_t i = 0; i < n; ++i) {
+            BSMR_HIP(hipSetDevice(s->devices[i]));
+            BSMR_HIP(hipEventRecord(s->start[i], s->streams[i]));
+            if (s->plans[i]) {
+                float* dst = i == 0 ? s->P[1][0] + s->entryBegin[0] : s->P[1][i];
+                if ((st = bsmr_sddmm(s->plans[i], K, s->A[i], s->B[i], dst, mode, s->streams[i])) != BSMR_OK) return st;
+            }
+            BSMR_HIP(hipEventRecord(s->stop[i], s->streams[i]));
+            BSMR_HIP(hipEventRecord(s->computed[1][i], s->streams[i]));
+        }
+        for (size_t i = 0; i < n; ++i) {
+            BSMR_HIP(hipSetDevice(s->devices[i]));
+            BSMR_HIP(hipEventSynchronize(s->stop[i]));
+            float ms = 0.0f;
+            BSMR_HIP(hipEventElapsedTime(&ms, s->start[i], s->stop[i]));
+            computeMs = std::max(computeMs, ms);
+        }
+        for (size_t i = 0; i < n; ++i) {
+            BSMR_HIP(hipSetDevice(s->devices[i]));
+            BSMR_HIP(hipEventRecord(s->gatherStart[i], s->gatherStreams[i]));
+        }
+        if ((st = shardedGather(s, 1)) != BSMR_OK) return st;
+        for (size_t i = 0; i < n; ++i) {
+            BSMR_HIP(hipSetDevice(s->devices[i]));
+            BSMR_HIP(hipEventRecord(s->stop[i], s->gatherStreams[i]));
+        }
+        for (size_t i = 0; i < n; ++i) {
+            BSMR_HIP(hipSetDevice(s->devices[i]));
+            BSMR_HIP(hipEventSynchronize(s->stop[i]));
+            float ms = 0.0f;
+            BSMR_HIP(hipEventElapsedTime(&ms, s->gatherStart[i], s->stop[i]));
+            gatherMs = std::max(gatherMs, ms);
+        }
+        if ((st = syncAll()) != BSMR_OK) return st;
+    }
+    // the timed steps, pipelined: step k computes into buffers k & 1 while the gather of step k - 1 delivers the others
     const auto t0 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < n; ++i) {
         BSMR_HIP(hipSetDevice(s->devices[i]));
         BSMR_HIP(hipEventRecord(s->start[i], s->streams[i]));
     }
-    for (int it = 0; it < iters && st == BSMR_OK; ++it) st = step();
+    for (int it = 0; it < iters && st == BSMR_OK; ++it) st = step(it & 1, true);
     if (st != BSMR_OK) return st;
     float maxMs = 0.0f;
-    for (size_t i = 0; i < n; ++i) {
+    for (size_t i = 0; i < n; ++i) {   // a step has ended when its part has reached the root: the stop events sit behind the last gather
         BSMR_HIP(hipSetDevice(s->devices[i]));
-        BSMR_HIP(hipEventRecord(s->stop[i], s->streams[i]));
+        BSMR_HIP(hipEventRecord(s->stop[i], s->gatherStreams[i]));
     }
     for (size_t i = 0; i < n; ++i) {
         BSMR_HIP(hipSetDevice(s->devices[i]));
@@ -309,13 +398,18 @@ int bsmr_sharded_sddmm_host(bsmr_sharded* s, uint32_t K, const float* A_host, co
         BSMR_HIP(hipEventElapsedTime(&ms, s->start[i], s->stop[i]));
         maxMs = std::max(maxMs, ms);
     }
+    if ((st = syncAll()) != BSMR_OK) return st;
     const double wallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     BSMR_HIP(hipSetDevice(s->devices[0]));
-    if (nnz) BSMR_HIP(hipMemcpy(P_host, s->P[0], nnz * 4, hipMemcpyDeviceToHost));
+    if (nnz) BSMR_HIP(hipMemcpy(P_host, s->P[(iters - 1) & 1][0], nnz * 4, hipMemcpyDeviceToHost));
     if (timing) {
-        timing->step_ms = maxMs / iters;
-        timing->wall_ms = (float)(wallMs / iters);
-        timing->num_devices = (uint32_t)n;
+        bsmr_sharded_timing t{};
+        t.step_ms = maxMs / iters;
+        t.wall_ms = (float)(wallMs / iters);
+        t.num_devices = (uint32_t)n;
+        t.compute_ms = computeMs;
+        t.gather_ms = gatherMs;
+        *timing = t;
     }
     return BSMR_OK;
 }

@@ -85,6 +85,7 @@ struct Logger {
     float delta_ = 0.0f;
     int numClusters_ = 1;
     float sddmmTime_ = 0.0f;
+    float shardComputeTime_ = 0.0f, shardGatherTime_ = 0.0f;   // sddmm_multi_gpu: one un-pipelined step taken apart (ms)
     float rowReorderingTime_ = 0.0f;
     float colReorderingTime_ = 0.0f;
     float reorderingTime_ = 0.0f;

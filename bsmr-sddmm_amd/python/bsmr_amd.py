@@ -115,7 +115,8 @@ class ColReorderSizes(C.Structure):
 
 
 class ShardedTiming(C.Structure):
-    _fields_ = [("step_ms", C.c_float), ("wall_ms", C.c_float), ("num_devices", C.c_uint32)]
+    _fields_ = [("step_ms", C.c_float), ("wall_ms", C.c_float), ("num_devices", C.c_uint32), ("compute_ms", C.c_float),
+                ("gather_ms", C.c_float)]
 
 
 class Timing(C.Structure):
@@ -127,6 +128,7 @@ class Timing(C.Structure):
 HIP_SYMBOLS = {
     "bsmr_strerror": (C.c_char_p, [C.c_int]),
     "bsmr_last_hip_error": (C.c_char_p, []),
+    "bsmr_abi_revision": (C.c_int, []),
     "bsmr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "bsmr_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "bsmr_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
@@ -224,6 +226,9 @@ HOST_SYMBOLS = {
     "bsmr_host_sddmm_sharded": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int,
                                           C.POINTER(C.c_int), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(C.c_float)]),
+    "bsmr_host_sddmm_sharded_timed": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int,
+                                                C.POINTER(C.c_int), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.POINTER(C.c_float)]),
     "bsmr_partition_rows_by_cost": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
 }
 
@@ -502,6 +507,18 @@ def partition_rows_by_cost(csr: CSR, world: int) -> list:
     b = (C.c_uint32 * (world + 1))()
     _check(host().bsmr_partition_rows_by_cost(csr.handle, world, b), "bsmr_partition_rows_by_cost")
     return [int(x) for x in b]
+
+
+def sddmm_operator_sharded_timed(csr: CSR, K: int, A, B, devices, alpha=0.3, delta=0.3, mode=COMPUTE_F16, iters=1):
+    """sddmm_multi_gpu on host operands -> (P, {step_ms (pipelined), compute_ms, gather_ms (one step taken apart)})"""
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    B = np.ascontiguousarray(B, dtype=np.float32)
+    P = np.empty(csr.nnz, dtype=np.float32)
+    devs = (C.c_int * len(devices))(*devices)
+    t = (C.c_float * 3)()
+    _check(host().bsmr_host_sddmm_sharded_timed(csr.handle, K, alpha, delta, mode, iters, devs, len(devices), _ptr(A), _ptr(B),
+                                                _ptr(P), t), "bsmr_host_sddmm_sharded_timed")
+    return P, {"step_ms": t[0], "compute_ms": t[1], "gather_ms": t[2]}
 
 
 def sddmm_operator_sharded(csr: CSR, K: int, A, B, devices, alpha=0.3, delta=0.3, mode=COMPUTE_F16, iters=1):

@@ -252,6 +252,15 @@ int bsmr_partition_rows_by_cost(const bsmr_csr* m, uint32_t world, uint32_t* bou
 int bsmr_host_sddmm_sharded(const bsmr_csr* m, uint32_t K, float alpha, float delta, int compute_mode, int num_iterations,
                             const int* devices, uint32_t num_devices, const float* A, const float* B, float* P,
                             float* step_ms) {
+    float t[3] = {0.f, 0.f, 0.f};
+    const int st = bsmr_host_sddmm_sharded_timed(m, K, alpha, delta, compute_mode, num_iterations, devices, num_devices, A, B, P, t);
+    if (step_ms) *step_ms = t[0];
+    return st;
+}
+
+int bsmr_host_sddmm_sharded_timed(const bsmr_csr* m, uint32_t K, float alpha, float delta, int compute_mode, int num_iterations,
+                                  const int* devices, uint32_t num_devices, const float* A, const float* B, float* P,
+                                  float* times_ms) {
     if (!m || !A || !B || !P || !devices || num_devices == 0) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || K % 32) return BSMR_ERR_UNSUPPORTED_K;
     return guarded([&]() -> int {
@@ -268,7 +277,11 @@ int bsmr_host_sddmm_sharded(const bsmr_csr* m, uint32_t K, float alpha, float de
         sddmm_multi_gpu(options, ma, mb, p, std::vector<int>(devices, devices + num_devices), logger);
         setSddmmComputeMode(before);
         memcpy(P, p.values().data(), p.values().size() * sizeof(float));
-        if (step_ms) *step_ms = logger.sddmmTime_;
+        if (times_ms) {
+            times_ms[0] = logger.sddmmTime_;
+            times_ms[1] = logger.shardComputeTime_;
+            times_ms[2] = logger.shardGatherTime_;
+        }
         return logger.status_;
     }, BSMR_ERR_OOM);
 }

@@ -187,6 +187,8 @@ void sddmm_multi_gpu(const Options& options, const Matrix<float>& matrixA, const
         st = bsmr_sharded_sddmm_host(sharded, K, matrixA.data(), matrixB.data(), matrixP.setValues().data(), sddmmComputeMode(),
                                      logger.numITER_ > 0 ? logger.numITER_ : 1, &t);
         logger.sddmmTime_ = t.step_ms;
+        logger.shardComputeTime_ = t.compute_ms;
+        logger.shardGatherTime_ = t.gather_ms;
     }
     if (st != BSMR_OK) fprintf(stderr, "sddmm_multi_gpu: %s (%s)\n", bsmr_strerror(st), bsmr_last_hip_error());
     bsmr_sharded_destroy(sharded);

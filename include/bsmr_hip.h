@@ -457,10 +457,19 @@ int bsmr_sddmm_lowp(bsmr_plan *plan, uint32_t K, const void *A16_dev, const void
  * hands its part over with a device-to-device copy.  A range without rows or entries takes no part in a step. */
 typedef struct bsmr_sharded bsmr_sharded;
 typedef struct bsmr_sharded_timing {
-    float    step_ms;      /* device time of one step (SDDMM on every device + gather), max over devices */
+    float    step_ms;      /* device time of one step (SDDMM on every device + gather), max over devices; the steps are
+                              pipelined over two sets of output buffers: the gather of step i runs behind the SDDMM of i + 1 */
     float    wall_ms;      /* host wall time of one step                                                  */
     uint32_t num_devices;
+    /* (round 4; appended - ABI revision 4) one un-pipelined step taken apart: */
+    float    compute_ms;   /* SDDMM alone, max over devices                                               */
+    float    gather_ms;    /* the gather-v alone: first part leaving to last part delivered               */
 } bsmr_sharded_timing;
+/* Revision of this header's struct layouts (4 = round 4: bsmr_sharded_timing, bsmr_tune_report, bsmr_cluster_stats and
+ * bsmr_plan_options grew at their ends).  A caller built against an older revision uses the *_sized entry points for the
+ * structs the library writes, or is rebuilt. */
+#define BSMR_ABI_REVISION 4
+int bsmr_abi_revision(void);
 int bsmr_sharded_create(bsmr_sharded **out, const int *devices, uint32_t num_devices,
                         const bsmr_rphm_desc *const *shard_descs, const uint32_t *row_begin,
                         const bsmr_plan_options *options);

@@ -125,6 +125,10 @@ int bsmr_host_sddmm(const bsmr_csr *m, uint32_t K, float alpha, float delta, int
 int bsmr_host_sddmm_sharded(const bsmr_csr *m, uint32_t K, float alpha, float delta, int compute_mode,
                             int num_iterations, const int *devices, uint32_t num_devices, const float *A,
                             const float *B, float *P, float *step_ms);
+/* ... with the step taken apart: times_ms[3] (may be NULL) = {one pipelined step, SDDMM alone (max over devices), gather-v alone} */
+int bsmr_host_sddmm_sharded_timed(const bsmr_csr *m, uint32_t K, float alpha, float delta, int compute_mode,
+                                  int num_iterations, const int *devices, uint32_t num_devices, const float *A,
+                                  const float *B, float *P, float *times_ms);
 int bsmr_partition_rows_by_cost(const bsmr_csr *m, uint32_t world, uint32_t *bounds);
 
 #ifdef __cplusplus

@@ -40,9 +40,11 @@ struct Variant {
     int KT, PM, NB, mode;
     bool src32;
     Kernel kernel;
+    bool shared = false;   // denseGemmCvt: one rounding per element through a second LDS image
 };
 #define V(name, KT, PM, NB, MODE) {name, KT, PM, NB, MODE, false, bsmr::denseGemm<KT, PM, NB, MODE, false>}
 #define V32(name, KT, PM, NB, MODE) {name, KT, PM, NB, MODE, true, bsmr::denseGemm<KT, PM, NB, MODE, true>}
+#define VC(name, KT, PM, NB, MODE) {name, KT, PM, NB, MODE, true, reinterpret_cast<Kernel>(bsmr::denseGemmCvt<KT, PM, NB, MODE>), true}
 static const Variant kVariants[] = {
     V("k512_b_256x256", 8, 16, 16, 1), V("k512_b_128x256", 8, 8, 16, 1), V("k512_b_256x128", 8, 16, 8, 1),
     V("k512_b_256x320", 8, 16, 20, 1), V("k512_b_256x192", 8, 16, 12, 1), V("k512_b_128x320", 8, 8, 20, 1),
@@ -53,6 +55,10 @@ static const Variant kVariants[] = {
     V32("k128_f32_256x256", 4, 16, 16, 0), V32("k128_f32_256x320", 4, 16, 20, 0), V32("k128_f32_128x256", 4, 8, 16, 0),
     V32("k128_f32_128x320", 4, 8, 20, 0), V32("k64_f32_256x256", 2, 16, 16, 0), V32("k32_f32_256x256", 1, 16, 16, 0),
     V32("k128_f32b_256x320", 4, 16, 20, 1),
+    // fp32 operands, one shared rounding per element (denseGemmCvt)
+    VC("k128_cvt_256x256", 4, 16, 16, 0), VC("k128_cvt_256x320", 4, 16, 20, 0), VC("k128_cvt_128x256", 4, 8, 16, 0),
+    VC("k128_cvt_128x320", 4, 8, 20, 0), VC("k64_cvt_256x320", 2, 16, 20, 0), VC("k128_cvtb_256x320", 4, 16, 20, 1),
+    VC("k32_cvt_256x320", 1, 16, 20, 0),
 };
 
 static uint16_t toF16(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
@@ -142,7 +148,7 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(dWords, f.words.data(), f.words.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemset(dP, 0xFF, (size_t)nnz * 4));
 
-    const size_t lds = bsmr::gemmLdsBytes(v->PM, v->NB);
+    const size_t lds = v->shared ? bsmr::gemmCvtLdsBytes(v->PM, v->NB) : bsmr::gemmLdsBytes(v->PM, v->NB);
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(v->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const bsmr::Batch batch{0, 0, 0, 1};
     const uint32_t full = f.fullGrid && !getenv("GEMM_ITEMS") ? 1u : 0u;   // GEMM_ITEMS=1: take the places from the item records
