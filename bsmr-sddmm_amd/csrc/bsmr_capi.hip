@@ -191,6 +191,8 @@ struct bsmr_plan {
     };
     std::unique_ptr<Retained> retained;
     bsmr_plan* delegate = nullptr;
+    uint64_t delegateKey = 0;      // ... the (K << 8 | mode) it was measured for: calls with another K or mode (exact fp32
+                                   // included, whose summation order follows the dense / residue split) stay with this plan
     int variantChosen = 0;         // BSMR_VARIANT_* of the plan that serves the calls
 };
 
@@ -204,6 +206,10 @@ constexpr uint64_t kGroupedGatherBytes = 400ull << 20;
 thread_local std::string g_lastHipError;
 inline bsmr_plan* served(bsmr_plan* p) { return p && p->delegate ? p->delegate : p; }
 inline const bsmr_plan* served(const bsmr_plan* p) { return p && p->delegate ? p->delegate : p; }
+// the plan that runs a call: the variant bsmr_plan_tune chose serves the (K, mode) it was timed for, nothing else
+inline bsmr_plan* servedFor(bsmr_plan* p, uint32_t K, int mode) {
+    return p && p->delegate && p->delegateKey == (((uint64_t)K << 8) | (uint32_t)mode) ? p->delegate : p;
+}
 // Where a launch goes: the stream and, for a batched call, the strides between the problems of the batch (grid y).
 struct Queue {
     hipStream_t stream = nullptr;
@@ -2489,9 +2495,11 @@ int bsmr_plan_dense_flags(const bsmr_plan* plan, uint8_t* flags_host) {
 }
 
 int bsmr_plan_reserve(bsmr_plan* plan, uint32_t K) {
-    plan = served(plan);
     if (!plan) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
+    if (plan->delegate) {   // (a variant serves the (K, mode) it was timed for, the plan itself every other call: both get their room)
+        if (int st = bsmr_plan_reserve(plan->delegate, K)) return st;
+    }
     BSMR_HIP(hipSetDevice(plan->device));
     if (int st = prepareDense(plan, K, BSMR_COMPUTE_F16)) return st;
     if (!convertPassOf(plan, K) && !convertsBOnly(plan, K)) return BSMR_OK;
@@ -2500,7 +2508,7 @@ int bsmr_plan_reserve(bsmr_plan* plan, uint32_t K) {
 
 int bsmr_sddmm(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode,
                void* stream) {
-    plan = served(plan);
+    plan = servedFor(plan, K, mode);
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     BSMR_HIP(hipSetDevice(plan->device));
@@ -2511,7 +2519,7 @@ int bsmr_sddmm(bsmr_plan* plan, uint32_t K, const float* A, const float* B, floa
 
 int bsmr_sddmm_batch(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, uint32_t num_batches,
                      int mode, void* stream) {
-    plan = served(plan);
+    plan = servedFor(plan, K, mode);
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     if (num_batches == 0) return BSMR_OK;
@@ -2557,7 +2565,7 @@ int bsmr_convert_operands(bsmr_plan* plan, uint32_t K, const float* A, const flo
 
 int bsmr_sddmm_lowp(bsmr_plan* plan, uint32_t K, const void* A16, const void* B16, const float* A,
                     const float* B, float* P, int mode, void* stream) {
-    plan = served(plan);
+    plan = servedFor(plan, K, mode);
     if (!plan || !A16 || !B16 || !P) return BSMR_ERR_INVALID_ARG;
     if (K == 0 || (K & 31u)) return BSMR_ERR_UNSUPPORTED_K;
     if (mode != BSMR_COMPUTE_F16 && mode != BSMR_COMPUTE_BF16) return BSMR_ERR_INVALID_ARG;
@@ -2581,7 +2589,7 @@ int bsmr_sddmm_lowp(bsmr_plan* plan, uint32_t K, const void* A16, const void* B1
 
 int bsmr_sddmm_timed(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float* P, int mode,
                      void* stream, int warmup, int iters, bsmr_timing* out) {
-    plan = served(plan);
+    plan = servedFor(plan, K, mode);
     int st = checkCall(plan, K, A, B, P, mode);
     if (st != BSMR_OK) return st;
     if (!out || iters <= 0 || warmup < 0) return BSMR_ERR_INVALID_ARG;
@@ -3012,7 +3020,14 @@ int tunePlan(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float*
             default: o.promote_average = 0; o.promote_head = 0; o.fold_dense_below = 0x7FFFFFFF; break;
         }
         bsmr_plan* alt = nullptr;
-        if ((st = bsmr_plan_create_ex(&alt, plan->device, &plan->retained->desc, &o)) != BSMR_OK) break;
+        // a variant that cannot be built or measured (no room for a third plan beside the two alive, a layout one of its
+        // engines refuses) is skipped - the rules' plan is tuned and usable; only a failing device ends the search
+        auto skippable = [](int e) { return e == BSMR_ERR_OOM || e == BSMR_ERR_BAD_PLAN || e == BSMR_ERR_UNSUPPORTED_K || e == BSMR_ERR_INVALID_ARG; };
+        if ((st = bsmr_plan_create_ex(&alt, plan->device, &plan->retained->desc, &o)) != BSMR_OK) {
+            if (!skippable(st)) break;
+            st = BSMR_OK;
+            continue;
+        }
         const Split split = splitOf(alt);
         if (std::find(seen.begin(), seen.end(), split) != seen.end()) {   // the same work as a plan already timed
             bsmr_plan_destroy(alt);
@@ -3024,7 +3039,11 @@ int tunePlan(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float*
             st = timeWholeCalls(alt, K, A, B, P, mode, s, &variantUs[v]);
         if (st != BSMR_OK) {
             bsmr_plan_destroy(alt);
-            break;
+            variantUs[v] = -1.f;
+            if (!skippable(st)) break;
+            (void)hipStreamSynchronize(s);
+            st = BSMR_OK;
+            continue;
         }
         if (variantUs[v] < bestUs) {
             if (best) bsmr_plan_destroy(best);
@@ -3041,6 +3060,7 @@ int tunePlan(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float*
         return st;
     }
     plan->delegate = best;
+    plan->delegateKey = ((uint64_t)K << 8) | (uint32_t)mode;
     plan->variantChosen = bestVariant;
     bestReport.chosen_variant = bestVariant;
     std::copy(variantUs, variantUs + 6, bestReport.variant_us);
@@ -3053,7 +3073,7 @@ int tunePlan(bsmr_plan* plan, uint32_t K, const float* A, const float* B, float*
 
 int bsmr_sddmm_host(bsmr_plan* plan, uint32_t K, const float* A_host, const float* B_host, float* P_host,
                     int mode, int iters, float* ms_per_iter) {
-    plan = served(plan);
+    plan = servedFor(plan, K, mode);
     int st = checkCall(plan, K, A_host, B_host, P_host, mode);
     if (st != BSMR_OK) return st;
     if (iters <= 0) iters = 1;

@@ -367,6 +367,7 @@ int bsmr_col_reorder_fetch(const bsmr_colreorder* h, uint32_t* dense_cols, uint3
                            uint32_t* block_values, uint32_t* sparse_values, uint32_t* sparse_relative_rows,
                            uint32_t* sparse_col_indices) {
     if (!h) return BSMR_ERR_INVALID_ARG;
+    DeviceRestore restore;   // (the calling thread's current device is the caller's business)
     BSMR_HIP(hipSetDevice(h->device));
     const size_t P1 = (size_t)h->numPanels + 1;
     auto host = [&](uint32_t* dst, const std::vector<uint32_t>& src) {

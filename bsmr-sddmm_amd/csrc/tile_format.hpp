@@ -82,13 +82,17 @@ inline int collectDense(const bsmr_rphm_desc* d, HostDense& out) {
         out.panelRows[i] = row;
     }
     out.offsets.assign((size_t)P + 1, 0);
-    for (uint32_t p = 0; p < P; ++p) {
+    for (uint32_t p = 0; p < P; ++p)
         if (d->block_offsets[p + 1] < d->block_offsets[p]) return BSMR_ERR_BAD_PLAN;
-        uint64_t n = 0;
-        for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b)
-            for (uint32_t i = 0; i < 256; ++i) n += d->block_values[b * 256 + i] != kNone;
-        out.offsets[p + 1] = n;
-    }
+    // (a sweep over all block values, 1 KiB per block: by all host threads - 22 MB for the nips-like plan, 5 of the 10 ms of this function)
+    parallelChunks(P, 4, [&](size_t p0, size_t p1, size_t) {
+        for (size_t p = p0; p < p1; ++p) {
+            uint64_t n = 0;
+            for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b)
+                for (uint32_t i = 0; i < 256; ++i) n += d->block_values[b * 256 + i] != kNone;
+            out.offsets[p + 1] = n;
+        }
+    });
     for (uint32_t p = 0; p < P; ++p) out.offsets[p + 1] += out.offsets[p];
     const uint64_t total = out.offsets[P];
     out.col.resize(total);

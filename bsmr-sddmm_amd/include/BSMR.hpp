@@ -13,6 +13,7 @@
 #include <string>
 #include <utility>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 struct bsmr_colreorder;   // include/bsmr_hip.h: a column-reordering result on the device
@@ -140,8 +141,10 @@ public:
 private:
     void release();
     // the column reordering ran on the device: block values and the residue arrays are copied to the host on first use
-    void fetchBigArrays() const;
+    int fetchBigArrays() const;   // bsmr_hip.h status; the arrays are empty when it failed
     mutable std::shared_ptr<bsmr_colreorder> onDevice_;
+    mutable std::mutex fetchLock_;
+    mutable int fetchStatus_ = 0;
 
     UIN numRowPanels_ = 0;
     UIN maxNumDenseColBlocksInRowPanel_ = 0;

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <numeric>
 
 #include "bsmr_hip.h"
@@ -234,13 +235,15 @@ RPHM::RPHM(const sparseMatrix::CSR<float>& matrix, const BSMR& bsmr, int device)
         if (onDevice_ && bsmr_col_reorder_device(onDevice_.get(), &where) == BSMR_OK && where == device) {
             // the plan from the arrays where the column reordering left them
             planStatus_ = bsmr_plan_create_from_colreorder(&plan_, onDevice_.get(), d.M, d.N, d.nnz, d.reordered_rows, d.num_nonzero_rows, nullptr);
+            // (the device arrays stay behind onDevice_ until somebody asks for the host copies - check_rphm, the density
+            // statistics - or this object goes; the BSMR object that produced them drops its own reference when it is re-split)
         } else {
-            fetchBigArrays();
+            planStatus_ = fetchBigArrays();
             d.block_values = blockValues_.data();
             d.sparse_values = sparseValues_.data();
             d.sparse_relative_rows = sparseRelativeRows_.data();
             d.sparse_col_indices = sparseColIndices_.data();
-            planStatus_ = bsmr_plan_create(&plan_, device, &d);
+            if (planStatus_ == BSMR_OK) planStatus_ = bsmr_plan_create(&plan_, device, &d);
         }
         if (planStatus_ != BSMR_OK) {
             fprintf(stderr, "RPHM: device plan creation failed: %s (%s)\n", bsmr_strerror(planStatus_),
@@ -250,19 +253,39 @@ RPHM::RPHM(const sparseMatrix::CSR<float>& matrix, const BSMR& bsmr, int device)
     }
 }
 
-void RPHM::fetchBigArrays() const {
-    if (!onDevice_) return;
-    const std::shared_ptr<bsmr_colreorder> h = std::move(onDevice_);
-    onDevice_.reset();
+int RPHM::fetchBigArrays() const {
+    // (called from const getters, possibly from several threads: one fetch, its status kept)
+    std::lock_guard<std::mutex> guard(fetchLock_);
+    if (!onDevice_) return fetchStatus_;
     bsmr_colreorder_sizes sz{};
-    if (bsmr_col_reorder_sizes(h.get(), &sz) != BSMR_OK) return;
-    blockValues_.resize(sz.num_blocks * BLOCK_SIZE);
-    sparseValues_.resize(sz.num_sparse_entries);
-    sparseRelativeRows_.resize(sz.num_sparse_entries);
-    sparseColIndices_.resize(sz.num_sparse_entries);
-    if (bsmr_col_reorder_fetch(h.get(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, blockValues_.data(), sparseValues_.data(),
-                               sparseRelativeRows_.data(), sparseColIndices_.data()) != BSMR_OK)
-        fprintf(stderr, "RPHM: fetching the device arrays failed: %s\n", bsmr_last_hip_error());
+    int st = bsmr_col_reorder_sizes(onDevice_.get(), &sz);
+    if (st == BSMR_OK) {
+        try {
+            blockValues_.resize(sz.num_blocks * BLOCK_SIZE);
+            sparseValues_.resize(sz.num_sparse_entries);
+            sparseRelativeRows_.resize(sz.num_sparse_entries);
+            sparseColIndices_.resize(sz.num_sparse_entries);
+        } catch (const std::bad_alloc&) {
+            st = BSMR_ERR_OOM;
+        }
+    }
+    if (st == BSMR_OK)
+        st = bsmr_col_reorder_fetch(onDevice_.get(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, blockValues_.data(), sparseValues_.data(),
+                                    sparseRelativeRows_.data(), sparseColIndices_.data());
+    if (st != BSMR_OK) {
+        // nothing half-filled stays behind (zero-filled arrays would read as "every dense cell is CSR entry 0"), the handle
+        // is kept: a later call may try again
+        fprintf(stderr, "RPHM: fetching the device arrays failed: %s (%s)\n", bsmr_strerror(st), bsmr_last_hip_error());
+        blockValues_.clear();
+        sparseValues_.clear();
+        sparseRelativeRows_.clear();
+        sparseColIndices_.clear();
+        fetchStatus_ = st;
+        return st;
+    }
+    onDevice_.reset();   // the device copy is not read again: the plan was built from it or will be built from the host arrays
+    fetchStatus_ = BSMR_OK;
+    return BSMR_OK;
 }
 
 void RPHM::release() {

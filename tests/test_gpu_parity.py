@@ -809,27 +809,33 @@ def test_tuned_plans_measure_the_dense_engines(engine, oracle):
             report = engine.plan_tune(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), mode, 0)
             torch.cuda.synchronize()
             print(f"K={K} mode={mode}: {report}")
-            families = {"stream": "stream", "grouped": "stream", "tiles": "tiles", "shared": "shared", "sweep": "sweep"}
+            families = {"stream": "stream", "grouped": "stream", "tiles": "tiles", "shared": "shared", "sweep": "sweep", "gemm": "gemm"}
             measured = {f: report[f + "_us"] for f in families if report[f + "_us"] >= 0}
             if K == 96:      # the tiles engines serve K in {32, 64, 128, 256, 512}: only the two formats of the streaming engine
                 assert report["chosen"] == "stream" and report["tiles_us"] < 0 and report["shared_us"] < 0 and report["sweep_us"] < 0
             else:
                 assert min(report["stream_us"], report["tiles_us"], report["shared_us"], report["sweep_us"]) > 0
-            if measured and report["cvt_in_kernel"] == 1:     # fp32 operands rounded in the kernel: the streaming or the sweep kernel
-                assert report["chosen"] in ("stream", "sweep") and (report["chosen"] == "sweep") == (report["sweep_fp32"] == 1)
-                if K <= 128 and report["sweep_fp32_call_us"] > 0:   # whole calls: what was chosen is not slower than the other (2 % margin)
+            if measured and report["cvt_in_kernel"] == 1:     # fp32 operands rounded in the kernel: the streaming, the sweep or the GEMM kernel
+                assert report["chosen"] in ("stream", "sweep", "gemm") and (report["chosen"] == "sweep") == (report["sweep_fp32"] == 1)
+                assert (report["chosen"] == "gemm") == (report["gemm_fp32"] == 1)
+                if report["gemm_fp32"]:      # whole calls: the GEMM kernel on fp32 operands beat the best of the rest by the margin
+                    others = [report[k] for k in ("lowp_call_us", "sweep_fp32_call_us") if report[k] > 0]
+                    assert report["gemm_fp32_call_us"] > 0 and report["gemm_fp32_call_us"] <= min(others) * 1.0, report
+                elif K <= 128 and report["sweep_fp32_call_us"] > 0:   # what was chosen is not slower than the other (2 % margin)
                     mine, other = (("sweep_fp32_call_us", "lowp_call_us") if report["sweep_fp32"] else ("lowp_call_us", "sweep_fp32_call_us"))
                     assert report[mine] <= report[other] * 1.03, report
             elif measured:
                 best = min(measured, key=measured.get)
                 mine = min(t for f, t in measured.items() if families[f] == report["chosen"])
                 assert report["chosen"] == families[best] or mine <= measured[best] * 1.03, report
-                assert (report["group"] > 1) == (best == "grouped") or best in ("tiles", "shared", "sweep"), report
+                assert (report["group"] > 1) == (best == "grouped") or best in ("tiles", "shared", "sweep", "gemm"), report
             assert report["b_only"] == -1 and report["overlap"] == -1      # an all-dense plan
             if K in (32, 64, 128):    # conversion pass + 16-bit kernel against the fp32-operand streaming kernel: whole call
                 assert min(report["convert_pass_us"], report["fp32_dense_us"]) > 0
                 chosen, other = ("fp32_dense_us", "convert_pass_us") if report["cvt_in_kernel"] == 1 else ("convert_pass_us", "fp32_dense_us")
-                assert report["cvt_in_kernel"] in (0, 1) and report[chosen] <= report[other] * 1.03    # (the rules' choice keeps a 2 % margin)
+                assert report["cvt_in_kernel"] in (0, 1)
+                if not report["sweep_fp32"] and not report["gemm_fp32"]:
+                    assert report[chosen] <= report[other] * 1.03    # (the rules' choice keeps a 2 % margin)
             else:
                 assert report["cvt_in_kernel"] == -1
             # (bf16 at K = 512 on U[0,2) data is inside the reference's tolerance)
