@@ -93,6 +93,7 @@ struct SweepFormatDev {
 struct GemmFormatDev {
     uint32_t PM = 0, NB = 0;   // panels / 16-column blocks per macro-tile
     uint32_t* panelRows = nullptr;
+    uint32_t* colOf = nullptr;
     bsmr::GemmItem* items = nullptr;
     uint32_t* rowStart = nullptr;
     uint32_t* lists = nullptr;
@@ -305,7 +306,7 @@ void freePlanDevice(bsmr_plan* p) {
     p->sweeps.clear();
     p->sweepNow = -1;
     for (GemmFormatDev& w : p->gemms) {
-        void* wp[] = {w.panelRows, w.items, w.rowStart, w.lists, w.words};
+        void* wp[] = {w.panelRows, w.colOf, w.items, w.rowStart, w.lists, w.words};
         for (void* q : wp)
             if (q) (void)hipFree(q);
     }
@@ -1285,7 +1286,7 @@ int ensureGemm(bsmr_plan* p, uint32_t K) {
         w.PM = PM;
         w.NB = NB;
         bsmr::GemmFormatHost host;
-        int st = bsmr::packGemm(p->hostDense, PM, NB, host);
+        int st = bsmr::packGemm(p->hostDense, PM, NB, host, p->opt.gemm_balance_columns != 0);
         if (st == BSMR_ERR_BAD_PLAN || st == BSMR_ERR_INVALID_ARG) {   // a shape this plan cannot take: remembered, the call uses another engine
             p->gemms.push_back(w);
             return BSMR_OK;
@@ -1298,12 +1299,13 @@ int ensureGemm(bsmr_plan* p, uint32_t K) {
         w.numTiles = host.numTiles;
         w.fullGrid = host.fullGrid;
         st = upload(w.panelRows, host.panelRows, bytes);
+        if (st == BSMR_OK) st = upload(w.colOf, host.colOf, bytes);
         if (st == BSMR_OK) st = upload(w.items, host.items, bytes);
         if (st == BSMR_OK) st = upload(w.rowStart, host.rowStart, bytes);
         if (st == BSMR_OK) st = upload(w.lists, host.lists, bytes);
         if (st == BSMR_OK) st = upload(w.words, host.words, bytes);
         if (st != BSMR_OK) {
-            void* wp[] = {w.panelRows, w.items, w.rowStart, w.lists, w.words};
+            void* wp[] = {w.panelRows, w.colOf, w.items, w.rowStart, w.lists, w.words};
             for (void* q : wp)
                 if (q) (void)hipFree(q);
             return st;
@@ -1331,12 +1333,12 @@ int launchGemmT(const GemmFormatDev& w, const bsmr_plan* p, const void* A, const
         const size_t lds = bsmr::gemmCvtLdsBytes(PM, NB);
         if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, p->device)) return st;
         hipLaunchKernelGGL(kernel, grid, block, lds, s, static_cast<const float*>(A), static_cast<const float*>(B), aBytes, bBytes, w.panelRows,
-                           w.items, w.rowStart, w.lists, w.words, P, p->N, w.numGroups, w.numStrips, w.fullGrid ? 1u : 0u, s.batch);
+                           w.colOf, w.items, w.rowStart, w.lists, w.words, P, p->N, w.numGroups, w.numStrips, w.fullGrid ? 1u : 0u, s.batch);
     } else {
         auto kernel = bsmr::denseGemm<KT, PM, NB, MODE, false>;
         const size_t lds = bsmr::gemmLdsBytes(PM, NB);
         if (int st = raiseDynamicLds(reinterpret_cast<const void*>(kernel), lds, p->device)) return st;
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, A, B, aBytes, bBytes, w.panelRows, w.items, w.rowStart, w.lists, w.words, P, p->N,
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, A, B, aBytes, bBytes, w.panelRows, w.colOf, w.items, w.rowStart, w.lists, w.words, P, p->N,
                            w.numGroups, w.numStrips, w.fullGrid ? 1u : 0u, s.batch);
     }
     BSMR_HIP(hipGetLastError());
@@ -1882,6 +1884,7 @@ int bsmr_plan_options_default(bsmr_plan_options* opt) {
     o.gemm_panels = 0;
     o.gemm_blocks = 0;
     o.gemm_fp32 = -1;
+    o.gemm_balance_columns = 1;
     *opt = o;
     return BSMR_OK;
 }
@@ -1910,7 +1913,7 @@ int bsmr_plan_options_from_env(bsmr_plan_options* opt) {
         {"BSMR_MASK_TILES", &o.mask_tiles}, {"BSMR_PACK_ON_DEVICE", &o.pack_on_device},
         {"BSMR_SWEEP_PANELS", &o.sweep_panels}, {"BSMR_SWEEP_BLOCKS", &o.sweep_strip_blocks}, {"BSMR_SWEEP_FP32", &o.sweep_fp32},
         {"BSMR_SWEEP_WAVES", &o.sweep_waves}, {"BSMR_SWEEP_PER_CU", &o.sweep_per_cu}, {"BSMR_K_HINT", &o.k_hint}, {"BSMR_PROMOTE_ON_DEVICE", &o.promote_on_device},
-        {"BSMR_GEMM_PANELS", &o.gemm_panels}, {"BSMR_GEMM_BLOCKS", &o.gemm_blocks}, {"BSMR_GEMM_FP32", &o.gemm_fp32},
+        {"BSMR_GEMM_PANELS", &o.gemm_panels}, {"BSMR_GEMM_BLOCKS", &o.gemm_blocks}, {"BSMR_GEMM_FP32", &o.gemm_fp32}, {"BSMR_GEMM_BALANCE_COLUMNS", &o.gemm_balance_columns},
     };
     for (const auto& k : knobs) *k.field = envInt(k.name, *k.field);
     return BSMR_OK;

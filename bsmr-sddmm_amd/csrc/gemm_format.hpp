@@ -12,6 +12,17 @@
 // carries its value to P.
 //
 //   panelRows [G * TM]        original row ids, 16 per panel, panels in RPHM order (padding: row 0 of the list)
+//   colOf     [S * TN]        the column of B in every column slot.  Slots follow the natural column order EXCEPT for hot
+//                             columns (more than twice the average number of dense entries), which are dealt over the S
+//                             strips by descending count (boustrophedon), so that no strip gathers them.  The MFMA work of a
+//                             macro-tile does not depend on what it holds, its mask epilogue is one store per entry: in
+//                             natural order the six macro-tiles of the nips-like pattern's first 320 columns (Zipf column
+//                             weights) hold 80 000 entries each against an average of 3 200, and the launch waits for
+//                             their epilogues (probe, K = 128: 32 us against 13).  B's columns are gathered by id like A's
+//                             rows (a column of the column-major B is K contiguous elements), so any order reads the same
+//                             bytes; what the order changes is how a row's entries of one macro-tile lie in P, hence
+//                             natural order for everything that is not hot.  Unused slots name column 0 (no entry refers
+//                             to them).
 //   items     [I]             {row group, first 16-column block, index of its first `lists` word}; macro-tiles WITHOUT a
 //                             dense entry are not listed.  Order (gemmItemPlace): column slabs of kGemmSlabStrips strips,
 //                             inside a slab row group by row group - a launch's eighth (what one XCD works on) is a few row
@@ -20,7 +31,7 @@
 //   rowStart  [I][TM]         smallest CSR index among the entries the item holds of that row (0 if none)
 //   lists     [I][W * Q + 1]  wave w, pass q: words[lists[w * Q + q] .. lists[w * Q + q + 1]); Q = ceil(m n / 16) passes;
 //                             every list is padded to a multiple of 4 words with kGemmNoEntry
-//   words     [u32]           one per stored dense entry, lists ordered by (row, column):
+//   words     [u32]           one per stored dense entry, lists ordered by (row, position in P):
 //                             slab slot (12 bits) | row in the wave's rows (7) << 12 | offset (13) << 19
 //                             slab slot = ((tile in pass) * 64 + 16 (r >> 2) + c) * 4 + (r & 3) for row r, column c of a
 //                             16 x 16 tile (the MFMA accumulator layout: lane 16 (r >> 2) + c, register r & 3); tile t of a
@@ -70,6 +81,7 @@ struct GemmFormatHost {
     uint32_t PM = 0, NB = 0, numGroups = 0, numStrips = 0, passes = 0;
     bool fullGrid = false;          // every macro-tile of the G x S grid is an item
     std::vector<uint32_t> panelRows;
+    std::vector<uint32_t> colOf;
     std::vector<GemmItem> items;
     std::vector<uint32_t> rowStart;
     std::vector<uint32_t> lists;
@@ -77,7 +89,7 @@ struct GemmFormatHost {
     uint64_t numTiles = 0;          // 16 x 16 tiles multiplied: items * PM * NB
     uint32_t maxListWords = 0;      // longest (wave, pass) list
     size_t bytes() const {
-        return 4 * (panelRows.size() + rowStart.size() + lists.size() + words.size()) + sizeof(GemmItem) * items.size();
+        return 4 * (panelRows.size() + colOf.size() + rowStart.size() + lists.size() + words.size()) + sizeof(GemmItem) * items.size();
     }
 };
 
@@ -86,8 +98,9 @@ inline bool gemmShapeOk(uint32_t PM, uint32_t NB) {
     return (PM == 8 || PM == 16) && (NB == 8 || NB == 12 || NB == 16 || NB == 20);
 }
 
-// Packs the dense entries for macro-tiles of PM panels x NB 16-column blocks.
-inline int packGemm(const HostDense& hd, uint32_t PM, uint32_t NB, GemmFormatHost& out) {
+// Packs the dense entries for macro-tiles of PM panels x NB 16-column blocks.  balanceColumns = false keeps the natural column
+// order (slot = column id).
+inline int packGemm(const HostDense& hd, uint32_t PM, uint32_t NB, GemmFormatHost& out, bool balanceColumns = true) {
     if (!gemmShapeOk(PM, NB)) return BSMR_ERR_INVALID_ARG;
     const uint32_t P = hd.numPanels, TM = PM * 16;
     const uint32_t G = (P + PM - 1) / PM, NCB = (hd.N + 15) / 16, S = (NCB + NB - 1) / NB;
@@ -98,12 +111,52 @@ inline int packGemm(const HostDense& hd, uint32_t PM, uint32_t NB, GemmFormatHos
     if ((uint64_t)G * S > 0x3FFFFFFFull || hd.entries() > 0xFFFFFFF0ull) return BSMR_ERR_INVALID_ARG;
     out.panelRows.assign((size_t)G * TM, hd.panelRows.empty() ? 0u : hd.panelRows[0]);
     std::copy(hd.panelRows.begin(), hd.panelRows.end(), out.panelRows.begin());
+    // 0. the slot of every column
+    const uint32_t TN = NB * 16;
+    std::vector<uint32_t> slotOf(hd.N);
+    out.colOf.assign((size_t)S * TN, 0u);
+    if (balanceColumns) {
+        // HOT columns - more than twice the average number of dense entries - are dealt over the strips by descending count,
+        // back and forth; the others fill the strips' remaining slots in natural order, so that what a row stores in a
+        // macro-tile stays a run of P wherever the pattern has no hot columns (a full permutation was measured: scattered
+        // stores cost a uniform pattern 3 - 5 us, 4096^2 K = 512: 17.8 -> 22.5 us)
+        std::vector<uint32_t> degree(hd.N, 0), hot;
+        for (uint64_t e = 0; e < hd.entries(); ++e) ++degree[hd.col[e]];
+        // ... and only where the natural order is lopsided: a strip of natural columns with more than twice the strips' mean
+        // (hot columns that lie scattered - the nips-like stand-in's do - balance the strips by themselves, and dealing them
+        // would only scatter their stores: 10.9 -> 15.0 us measured on it)
+        uint64_t fullest = 0;
+        for (uint32_t st = 0; st < S; ++st) {
+            uint64_t sum = 0;
+            for (uint32_t c = st * TN; c < std::min<uint64_t>(hd.N, (uint64_t)(st + 1) * TN); ++c) sum += degree[c];
+            fullest = std::max(fullest, sum);
+        }
+        const bool lopsided = fullest * S > 2ull * hd.entries();
+        const uint64_t threshold = lopsided ? 2ull * hd.entries() / std::max<uint32_t>(1u, hd.N) + 1ull : ~0ull;
+        for (uint32_t c = 0; c < hd.N; ++c)
+            if (degree[c] > threshold) hot.push_back(c);
+        std::stable_sort(hot.begin(), hot.end(), [&](uint32_t a, uint32_t b) { return degree[a] > degree[b]; });
+        std::vector<uint32_t> filled(S, 0);
+        for (uint32_t rank = 0; rank < hot.size(); ++rank) {   // round `rank / S` deals one column to every strip
+            const uint32_t round = rank / S, pos = rank % S, strip = (round & 1u) ? S - 1u - pos : pos;
+            slotOf[hot[rank]] = strip * TN + filled[strip]++;
+        }
+        uint32_t strip = 0;
+        for (uint32_t c = 0; c < hd.N; ++c) {
+            if (degree[c] > threshold) continue;
+            while (filled[strip] == TN) ++strip;   // (S * TN >= N slots in all)
+            slotOf[c] = strip * TN + filled[strip]++;
+        }
+    } else {
+        for (uint32_t c = 0; c < hd.N; ++c) slotOf[c] = c;
+    }
+    for (uint32_t c = 0; c < hd.N; ++c) out.colOf[slotOf[c]] = c;
     // 1. which macro-tiles hold entries, entries per (macro-tile, wave, pass) list
     std::vector<uint32_t> itemOf((size_t)G * S, 0xFFFFFFFFu);   // (g, s) -> item, assigned in super-tile order below
     std::vector<uint8_t> used((size_t)G * S, 0);
     for (uint32_t p = 0; p < P; ++p) {
         const uint32_t g = p / PM;
-        for (uint64_t e = hd.offsets[p]; e < hd.offsets[p + 1]; ++e) used[(size_t)g * S + (hd.col[e] >> 4) / NB] = 1;
+        for (uint64_t e = hd.offsets[p]; e < hd.offsets[p + 1]; ++e) used[(size_t)g * S + slotOf[hd.col[e]] / TN] = 1;
     }
     for (uint32_t i = 0; i < G * S; ++i) {   // the order of gemmItemPlace, macro-tiles without entries left out
         uint32_t g, st;
@@ -125,10 +178,11 @@ inline int packGemm(const HostDense& hd, uint32_t PM, uint32_t NB, GemmFormatHos
     out.rowStart.assign(I * TM, 0xFFFFFFFFu);
     auto locate = [&](uint32_t p, uint64_t e, size_t& item, uint32_t& list, uint32_t& slot, uint32_t& rowInWave, uint32_t& rowInTile) {
         const uint32_t g = p / PM, pj = p % PM;                       // panel pj of the group
-        const uint32_t cb = hd.col[e] >> 4, s = cb / NB, bj = cb % NB; // block bj of the macro-tile
+        const uint32_t slotCol = slotOf[hd.col[e]];
+        const uint32_t cb = slotCol >> 4, s = cb / NB, bj = cb % NB;  // block bj of the macro-tile
         const uint32_t wm = pj / m, tm = pj % m, wn = bj / n, tn = bj % n;
         const uint32_t t = tm * n + tn, q = t / kGemmPassTiles, tp = t % kGemmPassTiles;
-        const uint32_t r = hd.row[e], c = hd.col[e] & 15u;
+        const uint32_t r = hd.row[e], c = slotCol & 15u;
         item = itemOf[(size_t)g * S + s];
         list = (wm * kGemmWavesN + wn) * Q + q;
         slot = (tp * 64 + (r >> 2) * 16 + c) * 4 + (r & 3u);
@@ -174,8 +228,8 @@ inline int packGemm(const HostDense& hd, uint32_t PM, uint32_t NB, GemmFormatHos
             if (off >= kGemmMaxOffset) return BSMR_ERR_BAD_PLAN;
             const uint32_t word = slot | (rw << 12) | (off << 19);
             uint32_t& pos = fill[item * (L + 1) + list];
-            // key: row in wave (7 bits) | column inside the macro-tile (up to NB * 16 <= 512: 10 bits) | word
-            keys[e] = ((uint64_t)rw << 42) | ((uint64_t)(hd.col[e] - out.items[item].firstBlock * 16u) << 32) | word;
+            // key: row in wave (7 bits) | offset in the row's run of P (13 bits) | word: a list in (row, CSR position) order
+            keys[e] = ((uint64_t)rw << 45) | ((uint64_t)off << 32) | word;
             out.words[pos++] = (uint32_t)e;   // (the entry's number for now: replaced by the sorted words below)
         }
     std::vector<uint64_t> scratch;

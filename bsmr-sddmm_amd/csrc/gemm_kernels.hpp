@@ -78,19 +78,28 @@ __device__ __forceinline__ void gemmKeep(const u32x4& x) {
 // This wave's share of one stage: ADMAS + BDMAS LDS-DMA instructions of 1 KiB (8 rows of 128 bytes), voff = the lane's
 // byte offset of its piece in slice 0, kOff = the slice's byte offset inside a row.  (A function of its own: a buffer
 // resource cannot be captured by a lambda of a kernel that the host pass instantiates too.)
+template <uint32_t DMAS>
+__device__ __forceinline__ void gemmStagePart(const uint8_t* src, uint32_t srcBytes, uint8_t* dst, uint32_t wave, const uint32_t* voff, uint32_t kOff) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, srcBytes, 0x00020000);
+#pragma unroll
+    for (uint32_t j = 0; j < DMAS; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (wave * DMAS + j) * 1024u), 16, voff[j], kOff, 0, 0);
+}
 template <uint32_t ADMAS, uint32_t BDMAS>
 __device__ __forceinline__ void gemmStage(const uint8_t* A, uint32_t aBytes, const uint8_t* B, uint32_t bBytes, uint8_t* stage, uint32_t bAt,
                                           uint32_t wave, const uint32_t* voffA, const uint32_t* voffB, uint32_t kOff) {
-    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, aBytes, 0x00020000);
-    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(B), 0, bBytes, 0x00020000);
+    gemmStagePart<BDMAS>(B, bBytes, stage + bAt, wave, voffB, kOff);
+    gemmStagePart<ADMAS>(A, aBytes, stage, wave, voffA, kOff);
+}
+// Row id of this lane's row in a chunk of 8 rows whose ids lie at `rows8` (a wave-uniform address): eight SCALAR loads and a
+// select.  A vector load here would sit in the same in-order counter as the LDS-DMAs issued before it, and hipcc waits for
+// everything (vmcnt(0)) at its first use: the first stage's B columns, which do not depend on the row ids, would have to land
+// before the A rows are even requested.  Scalar loads count on lgkmcnt.
+__device__ __forceinline__ uint32_t gemmRowOfLane(const uint32_t* __restrict__ rows8, uint32_t sub) {
+    uint32_t id = rows8[0];
 #pragma unroll
-    for (uint32_t j = 0; j < BDMAS; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (__attribute__((address_space(3))) void*)(stage + bAt + (wave * BDMAS + j) * 1024u), 16,
-                                                 voffB[j], kOff, 0, 0);
-#pragma unroll
-    for (uint32_t j = 0; j < ADMAS; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(stage + (wave * ADMAS + j) * 1024u), 16, voffA[j],
-                                                 kOff, 0, 0);
+    for (uint32_t k = 1; k < 8; ++k) id = sub == k ? rows8[k] : id;
+    return id;
 }
 
 // grid: numItems x batches.  gridG / gridS: row groups / column strips of the format; fullGrid != 0: every macro-tile is an
@@ -99,7 +108,8 @@ __device__ __forceinline__ void gemmStage(const uint8_t* A, uint32_t aBytes, con
 template <int KT, int PM, int NB, int MODE, bool SRC32 = false>
 __global__ void __launch_bounds__(kGemmWaves * kWave, 2)
 denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t aBytes, uint32_t bBytes,
-          const uint32_t* __restrict__ panelRows, const GemmItem* __restrict__ items, const uint32_t* __restrict__ rowStart,
+          const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ colOf, const GemmItem* __restrict__ items,
+          const uint32_t* __restrict__ rowStart,
           const uint32_t* __restrict__ lists, const uint32_t* __restrict__ words, float* __restrict__ P, uint32_t N,
           uint32_t gridG, uint32_t gridS, uint32_t fullGrid, Batch batch GEMM_LAB_ARG) {
     constexpr uint32_t ESZ = SRC32 ? 4u : 2u, K = (kGemmRowBytes / ESZ) * KT, TM = PM * 16u, TN = NB * 16u;
@@ -137,18 +147,19 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
     // row 8 i + (l >> 3); the piece that belongs in that slot is slot ^ swz(row)
     uint32_t voffA[ADMAS], voffB[BDMAS];
 #pragma unroll
-    for (uint32_t j = 0; j < ADMAS; ++j) {
-        const uint32_t row = 8u * (wave * ADMAS + j) + (lane >> 3);
-        const uint32_t id = panelRows[(size_t)group * TM + row];
-        voffA[j] = id * (K * ESZ) + (((lane & 7u) ^ (SRC32 ? gemmSwz32(row) : gemmSwz16(row))) << 4);
-    }
-#pragma unroll
     for (uint32_t j = 0; j < BDMAS; ++j) {
         const uint32_t col = 8u * (wave * BDMAS + j) + (lane >> 3);
-        const uint32_t id = min(firstBlock * 16u + col, N - 1u);                 // the last block of B may be ragged
+        const uint32_t id = gemmRowOfLane(colOf + (size_t)firstBlock * 16u + 8u * (wave * BDMAS + j), lane >> 3);   // the column in this slot
         voffB[j] = id * (K * ESZ) + (((lane & 7u) ^ (SRC32 ? gemmSwz32(col) : gemmSwz16(col))) << 4);
     }
-    if (!GEMM_LAB_SKIP(2)) gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds, bAt, wave, voffA, voffB, 0u);
+    if (!GEMM_LAB_SKIP(2)) gemmStagePart<BDMAS>(Bb, bBytes, lds + bAt, wave, voffB, 0u);
+#pragma unroll
+    for (uint32_t j = 0; j < ADMAS; ++j) {
+        const uint32_t row = 8u * (wave * ADMAS + j) + (lane >> 3);
+        const uint32_t id = gemmRowOfLane(panelRows + (size_t)group * TM + 8u * (wave * ADMAS + j), lane >> 3);
+        voffA[j] = id * (K * ESZ) + (((lane & 7u) ^ (SRC32 ? gemmSwz32(row) : gemmSwz16(row))) << 4);
+    }
+    if (!GEMM_LAB_SKIP(2)) gemmStagePart<ADMAS>(Ab, aBytes, lds, wave, voffA, 0u);
     // the macro-tile's table of first indices, one row per thread
     if (threadIdx.x < TM) reinterpret_cast<uint32_t*>(lds + rowTableAt)[threadIdx.x] = rowStart[(size_t)itemId * TM + threadIdx.x];
     // entry lists of this wave: words[myList[q] .. myList[q + 1]) is pass q's
@@ -279,7 +290,8 @@ constexpr size_t gemmCvtLdsBytes(int PM, int NB) { return gemmCvtRingBytes(PM, N
 template <int KT, int PM, int NB, int MODE>
 __global__ void __launch_bounds__(kGemmWaves * kWave, 2)
 denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint32_t aBytes, uint32_t bBytes,
-             const uint32_t* __restrict__ panelRows, const GemmItem* __restrict__ items, const uint32_t* __restrict__ rowStart,
+             const uint32_t* __restrict__ panelRows, const uint32_t* __restrict__ colOf, const GemmItem* __restrict__ items,
+             const uint32_t* __restrict__ rowStart,
              const uint32_t* __restrict__ lists, const uint32_t* __restrict__ words, float* __restrict__ P, uint32_t N,
              uint32_t gridG, uint32_t gridS, uint32_t fullGrid, Batch batch GEMM_LAB_ARG) {
     constexpr uint32_t K = 32u * KT, TM = PM * 16u, TN = NB * 16u, ROWS = TM + TN;
@@ -314,16 +326,13 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
     uint32_t voffA[ADMAS], voffB[BDMAS];
     const uint32_t piece = lane & 7u;
 #pragma unroll
-    for (uint32_t j = 0; j < ADMAS; ++j) {
-        const uint32_t row = 8u * (wave * ADMAS + j) + (lane >> 3);
-        voffA[j] = panelRows[(size_t)group * TM + row] * (K * 4u) + (piece << 4);
-    }
+    for (uint32_t j = 0; j < BDMAS; ++j)
+        voffB[j] = gemmRowOfLane(colOf + (size_t)firstBlock * 16u + 8u * (wave * BDMAS + j), lane >> 3) * (K * 4u) + (piece << 4);
+    if (!GEMM_LAB_SKIP(2)) gemmStagePart<BDMAS>(Bb, bBytes, lds + bAtF, wave, voffB, 0u);
 #pragma unroll
-    for (uint32_t j = 0; j < BDMAS; ++j) {
-        const uint32_t col = 8u * (wave * BDMAS + j) + (lane >> 3);
-        voffB[j] = min(firstBlock * 16u + col, N - 1u) * (K * 4u) + (piece << 4);   // the last block of B may be ragged
-    }
-    if (!GEMM_LAB_SKIP(2)) gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds, bAtF, wave, voffA, voffB, 0u);
+    for (uint32_t j = 0; j < ADMAS; ++j)
+        voffA[j] = gemmRowOfLane(panelRows + (size_t)group * TM + 8u * (wave * ADMAS + j), lane >> 3) * (K * 4u) + (piece << 4);
+    if (!GEMM_LAB_SKIP(2)) gemmStagePart<ADMAS>(Ab, aBytes, lds, wave, voffA, 0u);
     if (threadIdx.x < TM) reinterpret_cast<uint32_t*>(lds + rowTableAt)[threadIdx.x] = rowStart[(size_t)itemId * TM + threadIdx.x];
     uint32_t myList[Q + 1];
 #pragma unroll

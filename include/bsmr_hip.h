@@ -220,6 +220,10 @@ typedef struct bsmr_plan_options {
     int32_t  gemm_fp32;             /* GEMM kernel on the caller's fp32 operands, rounded in registers (K = 64, 128; no
                                        conversion pass; a residue then runs its fp32 kernel): -1 = when the plan has no
                                        residue (default), 0 = never, 1 = whenever K allows                        [GEMM_FP32] */
+    int32_t  gemm_balance_columns;  /* 1 (default): the columns of B are dealt over the column strips by their number of dense
+                                       entries, so that every macro-tile's mask epilogue holds about as many entries (hot
+                                       columns - graphs, bag-of-words - otherwise gather in a few macro-tiles the launch waits
+                                       for); 0: natural column order                                   [GEMM_BALANCE_COLUMNS] */
 } bsmr_plan_options;
 int bsmr_plan_options_default(bsmr_plan_options *opt);
 /* defaults, then every BSMR_<NAME> variable that is set */

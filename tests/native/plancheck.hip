@@ -271,13 +271,13 @@ extern "C" int plancheck_sweep(const bsmr_rphm_desc* d, uint32_t W, uint32_t PW,
 // (item, wave, pass) list of its macro-tile / panel / column block, with the slab slot of its accumulator cell; the item
 // order is gemmItemPlace's; lists are ordered by (row, column).
 // out[0] items, [1] entries, [2] groups, [3] strips, [4] full grid, [5] bytes, [6] tiles, [7] longest list.
-extern "C" int plancheck_gemm(const bsmr_rphm_desc* d, uint32_t PM, uint32_t NB, uint64_t* out) {
+extern "C" int plancheck_gemm(const bsmr_rphm_desc* d, uint32_t PM, uint32_t NB, uint32_t balance, uint64_t* out) {
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     bsmr::HostDense hd;
     int st = bsmr::collectDense(d, hd);
     if (st != BSMR_OK) return 100 + st;
     bsmr::GemmFormatHost f;
-    st = bsmr::packGemm(hd, PM, NB, f);
+    st = bsmr::packGemm(hd, PM, NB, f, balance != 0);
     if (st != BSMR_OK) return 200 + st;
     out[0] = f.items.size(); out[1] = hd.entries(); out[2] = f.numGroups; out[3] = f.numStrips; out[4] = f.fullGrid;
     out[5] = f.bytes(); out[6] = f.numTiles; out[7] = f.maxListWords;
@@ -298,6 +298,27 @@ extern "C" int plancheck_gemm(const bsmr_rphm_desc* d, uint32_t PM, uint32_t NB,
     const uint32_t TM = PM * 16, m = PM / bsmr::kGemmWavesM, n = NB / bsmr::kGemmWavesN;
     const uint32_t Q = (m * n + bsmr::kGemmPassTiles - 1) / bsmr::kGemmPassTiles, L = bsmr::kGemmWaves * Q;
     if (f.passes != Q || f.panelRows.size() != (size_t)f.numGroups * TM) return 3;
+    // colOf: every column that holds a dense entry in exactly one slot (unused slots name column 0); natural order without
+    // balancing; with it, the strips' entry counts differ by at most two columns' worth (the columns were dealt by
+    // descending count, back and forth) - counted below from the lists themselves
+    if (f.colOf.size() != (size_t)f.numStrips * NB * 16) return 21;
+    std::vector<uint32_t> degree(d->N, 0);
+    uint32_t maxDegree = 0;
+    for (uint32_t v = 0; v < d->nnz; ++v)
+        if (wantCol[v] != kNone) maxDegree = std::max(maxDegree, ++degree[wantCol[v]]);
+    {
+        std::vector<uint32_t> slots(d->N, 0);
+        for (size_t q = 0; q < f.colOf.size(); ++q) {
+            const uint32_t c = f.colOf[q];
+            if (c >= d->N) return 22;
+            if (!balance && q < d->N && c != q) return 23;
+            ++slots[c];
+        }
+        for (uint32_t c = 1; c < d->N; ++c)
+            if (degree[c] ? slots[c] != 1 : slots[c] > 1) return 24;
+        if (slots[0] == 0) return 25;
+    }
+    std::vector<uint64_t> perStrip(f.numStrips, 0);
     if (f.rowStart.size() != f.items.size() * TM || f.lists.size() != f.items.size() * (L + 1)) return 4;
     if (f.fullGrid != (f.items.size() == (size_t)f.numGroups * f.numStrips)) return 5;
     std::vector<uint8_t> seen(d->nnz, 0);
@@ -342,11 +363,12 @@ extern "C" int plancheck_gemm(const bsmr_rphm_desc* d, uint32_t PM, uint32_t NB,
                     const uint32_t idx = f.rowStart[it * TM + rowInTile] + off;
                     if (off >= bsmr::kGemmMaxOffset || idx >= d->nnz || seen[idx]++) return 14;
                     if (f.panelRows[(size_t)item.group * TM + rowInTile] != wantRow[idx]) return 15;
-                    if (item.firstBlock * 16 + colInTile != wantCol[idx]) return 16;
-                    const uint64_t key = ((uint64_t)rw << 32) | colInTile;
-                    if (i > b && key < lastKey) return 17;   // (row, column) order; repeated (row, column) pairs may follow each other
+                    if (f.colOf[(size_t)item.firstBlock * 16 + colInTile] != wantCol[idx]) return 16;
+                    const uint64_t key = ((uint64_t)rw << 32) | off;
+                    if (i > b && key < lastKey) return 17;   // (row, position in P) order
                     lastKey = key;
                     ++itemEntries;
+                    ++perStrip[item.firstBlock / NB];
                 }
             }
         if (itemEntries == 0) return 18;   // macro-tiles without entries are not items
@@ -354,5 +376,29 @@ extern "C" int plancheck_gemm(const bsmr_rphm_desc* d, uint32_t PM, uint32_t NB,
     if (f.words.size() < expectStart + bsmr::kGemmWordSlack) return 19;
     for (uint32_t v = 0; v < d->nnz; ++v)
         if ((wantRow[v] != kNone) != (seen[v] != 0)) return 20;
+    out[8] = *std::max_element(perStrip.begin(), perStrip.end());
+    out[9] = *std::min_element(perStrip.begin(), perStrip.end());
+    // where the natural order is lopsided (a natural strip above twice the mean), hot columns (more than twice the average
+    // count) are dealt evenly and the others lie in natural order: no strip then holds more than its even share of the hot
+    // entries (within two columns' worth) plus a full strip of columns at the threshold; otherwise the order is the natural one
+    {
+        const uint32_t S = f.numStrips, TN = NB * 16;
+        uint64_t fullest = 0;
+        for (uint32_t st = 0; st < S; ++st) {
+            uint64_t sum = 0;
+            for (uint64_t c = (uint64_t)st * TN; c < std::min<uint64_t>(d->N, (uint64_t)(st + 1) * TN); ++c) sum += degree[c];
+            fullest = std::max(fullest, sum);
+        }
+        const bool lopsided = fullest * S > 2ull * denseEntries;
+        out[10] = lopsided;
+        const uint64_t threshold = 2ull * denseEntries / std::max<uint32_t>(1u, d->N) + 1ull;
+        uint64_t hotEntries = 0;
+        for (uint32_t c = 0; c < d->N; ++c)
+            if (degree[c] > threshold) hotEntries += degree[c];
+        if (balance && lopsided && out[8] > hotEntries / S + 2ull * maxDegree + (uint64_t)TN * threshold) return 26;
+        if (balance && !lopsided)
+            for (uint32_t c = 0; c < d->N; ++c)
+                if (f.colOf[c] != c) return 27;
+    }
     return 0;
 }

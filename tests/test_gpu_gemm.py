@@ -128,12 +128,15 @@ def test_gemm_engine_full_matrix_lists_of_more_than_512_entries(engine, oracle, 
     check_case(engine, oracle, rows, cols, ro, ci, 128, 0.3, 0.0, 0)
     monkeypatch.setenv("BSMR_GEMM_PANELS", "8")
     monkeypatch.setenv("BSMR_GEMM_BLOCKS", "16")
+    monkeypatch.setenv("BSMR_GEMM_BALANCE_COLUMNS", "0")     # natural column order: the off-diagonal macro-tiles stay empty
     entries = [(i, j) for i in range(600) for j in range((i // 150) * 400, (i // 150) * 400 + 400, 7)]
     ro = np.zeros(601, dtype=np.uint32)
     for i, _ in entries:
         ro[i + 1] += 1
     ro = np.cumsum(ro).astype(np.uint32)
     ci = np.array([j for _, j in entries], dtype=np.uint32)
+    check_case(engine, oracle, 600, 1600, ro, ci, 64, 0.3, 0.0, 0, row_mode=engine.ROWS_IDENTITY)
+    monkeypatch.setenv("BSMR_GEMM_BALANCE_COLUMNS", "1")
     check_case(engine, oracle, 600, 1600, ro, ci, 64, 0.3, 0.0, 0, row_mode=engine.ROWS_IDENTITY)
 
 

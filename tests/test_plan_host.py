@@ -68,7 +68,7 @@ def tilecheck(engine):
         d.block_offsets, d.block_values = cast(keep["blockOffsets"]), cast(keep["blockValues"])
         d.sparse_value_offsets, d.sparse_values = cast(keep["sparseValueOffsets"]), cast(keep["sparseValues"])
         d.sparse_relative_rows, d.sparse_col_indices = cast(keep["sparseRelativeRows"]), cast(keep["sparseColIndices"])
-        out = (C.c_uint64 * 10)()
+        out = (C.c_uint64 * 11)()
         rc = lib.plancheck_tiles(C.byref(d), H, blocks_per_item, out)
         names = ("blocks", "tiles", "union_columns", "entries", "items", "entry_cap", "bytes", "census_blocks",
                  "census_tiles", "census_columns")
@@ -234,9 +234,9 @@ def test_sweep_format_rejects_shapes_it_cannot_hold(sweepcheck):
 def gemmcheck(engine):
     lib = C.CDLL(str(REPO / "tests" / "native" / "libplancheck.so"))
     lib.plancheck_gemm.restype = C.c_int
-    lib.plancheck_gemm.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    lib.plancheck_gemm.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
 
-    def run(rows, cols, ro, ci, alpha, delta, panels, blocks):
+    def run(rows, cols, ro, ci, alpha, delta, panels, blocks, balance=1):
         csr = engine.CSR.from_arrays(rows, cols, ro, ci)
         pipe = engine.Pipeline(csr, alpha=alpha, delta=delta, device=-1)
         arrays = pipe.arrays()
@@ -252,9 +252,10 @@ def gemmcheck(engine):
         d.block_offsets, d.block_values = cast(keep["blockOffsets"]), cast(keep["blockValues"])
         d.sparse_value_offsets, d.sparse_values = cast(keep["sparseValueOffsets"]), cast(keep["sparseValues"])
         d.sparse_relative_rows, d.sparse_col_indices = cast(keep["sparseRelativeRows"]), cast(keep["sparseColIndices"])
-        out = (C.c_uint64 * 8)()
-        rc = lib.plancheck_gemm(C.byref(d), panels, blocks, out)
-        res = dict(zip(("items", "entries", "groups", "strips", "full_grid", "bytes", "tiles", "longest_list"), (int(v) for v in out)))
+        out = (C.c_uint64 * 11)()
+        rc = lib.plancheck_gemm(C.byref(d), panels, blocks, balance, out)
+        res = dict(zip(("items", "entries", "groups", "strips", "full_grid", "bytes", "tiles", "longest_list", "fullest_strip", "emptiest_strip", "lopsided"),
+                       (int(v) for v in out)))
         res["rphm_dense"] = int(csr.nnz - keep["sparseValues"].size)
         return rc, res
     return run
@@ -267,8 +268,8 @@ def test_gemm_format_lists_every_dense_entry_once(gemmcheck, panels, blocks):
     (row, column) order - all-dense and hybrid plans, a ragged last row group (21 panels) and a ragged last column
     block (1500 = 93 * 16 + 12)."""
     rows, cols, ro, ci = synth.nips_like(rows=330, cols=1500, nnz=42000, seed=3)
-    for delta in (0.0, 0.1):
-        rc, r = gemmcheck(rows, cols, ro, ci, 0.3, delta, panels, blocks)
+    for delta, balance in ((0.0, 1), (0.1, 1), (0.0, 0)):
+        rc, r = gemmcheck(rows, cols, ro, ci, 0.3, delta, panels, blocks, balance)
         assert rc == 0, f"invariant {rc} violated: {r}"
         assert r["entries"] == r["rphm_dense"] > 0
         assert r["groups"] == -(-21 // panels) and r["strips"] == -(-94 // blocks)
@@ -299,8 +300,20 @@ def test_gemm_format_takes_unsorted_rows_full_tiles_and_empty_macro_tiles(gemmch
         ro[i + 1] += 1
     ro = np.cumsum(ro).astype(np.uint32)
     ci = np.array([j for _, j in blocks], dtype=np.uint32)
-    rc, r = gemmcheck(600, 1600, ro, ci, 0.3, 0.0, 8, 8)
+    rc, r = gemmcheck(600, 1600, ro, ci, 0.3, 0.0, 8, 8, balance=0)
     assert rc == 0 and r["full_grid"] == 0 and 0 < r["items"] < r["groups"] * r["strips"], (rc, r)
+    rc, r = gemmcheck(600, 1600, ro, ci, 0.3, 0.0, 8, 8, balance=1)     # (no natural strip above twice the mean: natural order stays)
+    assert rc == 0 and r["full_grid"] == 0 and r["lopsided"] == 0, (rc, r)
+    # hot columns FIRST (a vocabulary sorted by frequency): the first natural strip holds most entries, balancing deals them out
+    rows, cols = 512, 4096
+    per_row = [np.unique(np.concatenate([np.arange(0, 200, 1 + (i % 2)), (np.arange(40) * 97 + 13 * i) % cols])) for i in range(rows)]
+    ro = np.zeros(rows + 1, dtype=np.uint32)
+    ro[1:] = np.cumsum([c.size for c in per_row])
+    ci = np.concatenate(per_row).astype(np.uint32)
+    natural = gemmcheck(rows, cols, ro, ci, 0.3, 0.0, 16, 16, balance=0)
+    dealt = gemmcheck(rows, cols, ro, ci, 0.3, 0.0, 16, 16, balance=1)
+    assert natural[0] == 0 and dealt[0] == 0, (natural, dealt)
+    assert dealt[1]["lopsided"] == 1 and dealt[1]["fullest_strip"] * 3 < natural[1]["fullest_strip"], (natural[1], dealt[1])
 
 
 def test_gemm_format_rejects_shapes_it_cannot_hold(gemmcheck):

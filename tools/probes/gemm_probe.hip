@@ -27,11 +27,11 @@
 
 using bsmr::GemmItem;
 #ifdef BSMR_GEMM_LAB
-typedef void (*Kernel)(const void*, const void*, uint32_t, uint32_t, const uint32_t*, const GemmItem*, const uint32_t*,
+typedef void (*Kernel)(const void*, const void*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, const GemmItem*, const uint32_t*,
                        const uint32_t*, const uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, bsmr::Batch, uint32_t);
 #define LAB_ARGS , skip
 #else
-typedef void (*Kernel)(const void*, const void*, uint32_t, uint32_t, const uint32_t*, const GemmItem*, const uint32_t*,
+typedef void (*Kernel)(const void*, const void*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, const GemmItem*, const uint32_t*,
                        const uint32_t*, const uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, bsmr::Batch);
 #define LAB_ARGS
 #endif
@@ -91,9 +91,21 @@ int main(int argc, char** argv) {
     std::mt19937 rng(4);
     std::bernoulli_distribution coin(density);
     std::vector<uint32_t> ro(M + 1, 0), ci;
+    const bool zipf = getenv("GEMM_ZIPF") != nullptr;   // column j kept with probability min(1, c / (j + 1)): hot first columns (nips-like)
+    double zc = 0;
+    if (zipf) {   // c such that the expected row length is density * N
+        double lo = 0, hi = N;
+        for (int it = 0; it < 60; ++it) {
+            zc = 0.5 * (lo + hi);
+            double sum = 0;
+            for (uint32_t j = 0; j < N; ++j) sum += std::min(1.0, zc / (j + 1));
+            (sum < density * N ? lo : hi) = zc;
+        }
+    }
+    std::uniform_real_distribution<double> uni(0.0, 1.0);
     for (uint32_t i = 0; i < M; ++i) {
         for (uint32_t j = 0; j < N; ++j)
-            if (coin(rng)) ci.push_back(j);
+            if (zipf ? uni(rng) < std::min(1.0, zc / (j + 1)) : coin(rng)) ci.push_back(j);
         ro[i + 1] = (uint32_t)ci.size();
     }
     const uint32_t nnz = (uint32_t)ci.size();
@@ -115,7 +127,7 @@ int main(int argc, char** argv) {
         hd.offsets[p + 1] = hd.col.size();
     }
     bsmr::GemmFormatHost f;
-    const int st = bsmr::packGemm(hd, v->PM, v->NB, f);
+    const int st = bsmr::packGemm(hd, v->PM, v->NB, f, !getenv("GEMM_NATURAL"));   // GEMM_NATURAL=1: columns in natural order
     if (st != BSMR_OK) {
         fprintf(stderr, "packGemm: %d\n", st);
         return 1;
@@ -132,11 +144,13 @@ int main(int argc, char** argv) {
 
     uint8_t *dA, *dB;
     const size_t esz = v->src32 ? 4 : 2;
-    uint32_t *dRows, *dRowStart, *dLists, *dWords;
+    uint32_t *dRows, *dColOf, *dRowStart, *dLists, *dWords;
     GemmItem* dItems;
     float* dP;
     CHECK(hipMalloc(&dA, A16.size() * esz)); CHECK(hipMalloc(&dB, B16.size() * esz));
     CHECK(hipMalloc(&dRows, f.panelRows.size() * 4)); CHECK(hipMalloc(&dItems, f.items.size() * sizeof(GemmItem)));
+    CHECK(hipMalloc(&dColOf, f.colOf.size() * 4));
+    CHECK(hipMemcpy(dColOf, f.colOf.data(), f.colOf.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&dRowStart, f.rowStart.size() * 4)); CHECK(hipMalloc(&dLists, f.lists.size() * 4));
     CHECK(hipMalloc(&dWords, f.words.size() * 4)); CHECK(hipMalloc(&dP, (size_t)nnz * 4));
     CHECK(hipMemcpy(dA, v->src32 ? (const void*)A32.data() : (const void*)A16.data(), A16.size() * esz, hipMemcpyHostToDevice));
@@ -154,7 +168,7 @@ int main(int argc, char** argv) {
     const uint32_t full = f.fullGrid && !getenv("GEMM_ITEMS") ? 1u : 0u;   // GEMM_ITEMS=1: take the places from the item records
     auto launch = [&]() {
         hipLaunchKernelGGL(v->kernel, dim3((uint32_t)f.items.size()), dim3(512), lds, nullptr, dA, dB, (uint32_t)(A16.size() * esz),
-                           (uint32_t)(B16.size() * esz), dRows, dItems, dRowStart, dLists, dWords, dP, N, f.numGroups, f.numStrips, full, batch LAB_ARGS);
+                           (uint32_t)(B16.size() * esz), dRows, dColOf, dItems, dRowStart, dLists, dWords, dP, N, f.numGroups, f.numStrips, full, batch LAB_ARGS);
     };
     launch();
     CHECK(hipGetLastError());
