@@ -11,7 +11,12 @@
 // engines: a wave drops its accumulators into a private LDS slab (16 tiles at a time: a PASS) and one lane per STORED entry
 // carries its value to P.
 //
-//   panelRows [G * TM]        original row ids, 16 per panel, panels in RPHM order (padding: row 0 of the list)
+//   panelRows [G * TM]        original row ids of every macro-tile row.  NOT the RPHM's panel order: rows are dealt over the
+//                             2 G row halves (a half = the rows of one wave row) by descending number of dense entries,
+//                             back and forth, so that every wave's entry lists are about equally long - the clustered
+//                             order puts heavy rows side by side (nips-like: 198 k entries in one row group, 44 k in
+//                             another; the fullest wave three times the mean).  Rows of A are gathered by id and a row's
+//                             entries are a run of P wherever the row sits, so the order is free (padding: row 0 of the list)
 //   colOf     [S * TN]        the column of B in every column slot.  Slots follow the natural column order EXCEPT for hot
 //                             columns (more than twice the average number of dense entries), which are dealt over the S
 //                             strips by descending count (boustrophedon), so that no strip gathers them.  The MFMA work of a
@@ -110,7 +115,23 @@ inline int packGemm(const HostDense& hd, uint32_t PM, uint32_t NB, GemmFormatHos
     if (P == 0 || NCB == 0 || hd.entries() == 0) return BSMR_OK;
     if ((uint64_t)G * S > 0x3FFFFFFFull || hd.entries() > 0xFFFFFFF0ull) return BSMR_ERR_INVALID_ARG;
     out.panelRows.assign((size_t)G * TM, hd.panelRows.empty() ? 0u : hd.panelRows[0]);
-    std::copy(hd.panelRows.begin(), hd.panelRows.end(), out.panelRows.begin());
+    // 0a. the place of every row: rowPos[panel * 16 + row in panel] = group * TM + row in macro-tile
+    std::vector<uint32_t> rowPos((size_t)P * 16);
+    if (balanceColumns) {
+        std::vector<uint32_t> weight((size_t)P * 16, 0), order((size_t)P * 16);
+        for (uint32_t p = 0; p < P; ++p)
+            for (uint64_t e = hd.offsets[p]; e < hd.offsets[p + 1]; ++e) ++weight[(size_t)p * 16 + hd.row[e]];
+        for (uint32_t i = 0; i < P * 16; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+        const uint32_t bins = 2 * G, half = TM / 2;
+        for (uint32_t rank = 0; rank < P * 16; ++rank) {   // round `rank / bins` gives one row to every half
+            const uint32_t round = rank / bins, pos = rank % bins, bin = (round & 1u) ? bins - 1u - pos : pos;
+            rowPos[order[rank]] = (bin / 2) * TM + (bin % 2) * half + round;
+        }
+    } else {
+        for (uint32_t i = 0; i < P * 16; ++i) rowPos[i] = i;
+    }
+    for (uint32_t i = 0; i < P * 16; ++i) out.panelRows[rowPos[i]] = hd.panelRows[i];
     // 0. the slot of every column
     const uint32_t TN = NB * 16;
     std::vector<uint32_t> slotOf(hd.N);
@@ -154,10 +175,9 @@ inline int packGemm(const HostDense& hd, uint32_t PM, uint32_t NB, GemmFormatHos
     // 1. which macro-tiles hold entries, entries per (macro-tile, wave, pass) list
     std::vector<uint32_t> itemOf((size_t)G * S, 0xFFFFFFFFu);   // (g, s) -> item, assigned in super-tile order below
     std::vector<uint8_t> used((size_t)G * S, 0);
-    for (uint32_t p = 0; p < P; ++p) {
-        const uint32_t g = p / PM;
-        for (uint64_t e = hd.offsets[p]; e < hd.offsets[p + 1]; ++e) used[(size_t)g * S + slotOf[hd.col[e]] / TN] = 1;
-    }
+    for (uint32_t p = 0; p < P; ++p)
+        for (uint64_t e = hd.offsets[p]; e < hd.offsets[p + 1]; ++e)
+            used[(size_t)(rowPos[(size_t)p * 16 + hd.row[e]] / TM) * S + slotOf[hd.col[e]] / TN] = 1;
     for (uint32_t i = 0; i < G * S; ++i) {   // the order of gemmItemPlace, macro-tiles without entries left out
         uint32_t g, st;
         gemmItemPlace(i, G, S, g, st);
@@ -177,12 +197,13 @@ inline int packGemm(const HostDense& hd, uint32_t PM, uint32_t NB, GemmFormatHos
     out.lists.assign(I * (L + 1), 0);
     out.rowStart.assign(I * TM, 0xFFFFFFFFu);
     auto locate = [&](uint32_t p, uint64_t e, size_t& item, uint32_t& list, uint32_t& slot, uint32_t& rowInWave, uint32_t& rowInTile) {
-        const uint32_t g = p / PM, pj = p % PM;                       // panel pj of the group
+        const uint32_t place = rowPos[(size_t)p * 16 + hd.row[e]];
+        const uint32_t g = place / TM, pj = (place % TM) / 16u;      // row group, 16-row tile pj of the macro-tile
         const uint32_t slotCol = slotOf[hd.col[e]];
         const uint32_t cb = slotCol >> 4, s = cb / NB, bj = cb % NB;  // block bj of the macro-tile
         const uint32_t wm = pj / m, tm = pj % m, wn = bj / n, tn = bj % n;
         const uint32_t t = tm * n + tn, q = t / kGemmPassTiles, tp = t % kGemmPassTiles;
-        const uint32_t r = hd.row[e], c = slotCol & 15u;
+        const uint32_t r = place & 15u, c = slotCol & 15u;
         item = itemOf[(size_t)g * S + s];
         list = (wm * kGemmWavesN + wn) * Q + q;
         slot = (tp * 64 + (r >> 2) * 16 + c) * 4 + (r & 3u);

@@ -128,7 +128,7 @@ def test_gemm_engine_full_matrix_lists_of_more_than_512_entries(engine, oracle, 
     check_case(engine, oracle, rows, cols, ro, ci, 128, 0.3, 0.0, 0)
     monkeypatch.setenv("BSMR_GEMM_PANELS", "8")
     monkeypatch.setenv("BSMR_GEMM_BLOCKS", "16")
-    monkeypatch.setenv("BSMR_GEMM_BALANCE_COLUMNS", "0")     # natural column order: the off-diagonal macro-tiles stay empty
+    monkeypatch.setenv("BSMR_GEMM_BALANCE_COLUMNS", "0")     # natural row and column order: the off-diagonal macro-tiles stay empty
     entries = [(i, j) for i in range(600) for j in range((i // 150) * 400, (i // 150) * 400 + 400, 7)]
     ro = np.zeros(601, dtype=np.uint32)
     for i, _ in entries:

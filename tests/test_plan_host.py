@@ -302,8 +302,10 @@ def test_gemm_format_takes_unsorted_rows_full_tiles_and_empty_macro_tiles(gemmch
     ci = np.array([j for _, j in blocks], dtype=np.uint32)
     rc, r = gemmcheck(600, 1600, ro, ci, 0.3, 0.0, 8, 8, balance=0)
     assert rc == 0 and r["full_grid"] == 0 and 0 < r["items"] < r["groups"] * r["strips"], (rc, r)
-    rc, r = gemmcheck(600, 1600, ro, ci, 0.3, 0.0, 8, 8, balance=1)     # (no natural strip above twice the mean: natural order stays)
-    assert rc == 0 and r["full_grid"] == 0 and r["lopsided"] == 0, (rc, r)
+    # (balanced: no natural strip above twice the mean, so the columns stay in natural order; the ROWS are dealt over the row
+    # halves by entry count, which spreads the diagonal blocks over all macro-tiles)
+    rc, r = gemmcheck(600, 1600, ro, ci, 0.3, 0.0, 8, 8, balance=1)
+    assert rc == 0 and r["lopsided"] == 0 and r["full_grid"] == 1, (rc, r)
     # hot columns FIRST (a vocabulary sorted by frequency): the first natural strip holds most entries, balancing deals them out
     rows, cols = 512, 4096
     per_row = [np.unique(np.concatenate([np.arange(0, 200, 1 + (i % 2)), (np.arange(40) * 97 + 13 * i) % cols])) for i in range(rows)]
