@@ -58,7 +58,8 @@ static const Variant kVariants[] = {
     // fp32 operands, one shared rounding per element (denseGemmCvt)
     VC("k128_cvt_256x256", 4, 16, 16, 0), VC("k128_cvt_256x320", 4, 16, 20, 0), VC("k128_cvt_128x256", 4, 8, 16, 0),
     VC("k128_cvt_128x320", 4, 8, 20, 0), VC("k64_cvt_256x320", 2, 16, 20, 0), VC("k128_cvtb_256x320", 4, 16, 20, 1),
-    VC("k32_cvt_256x320", 1, 16, 20, 0),
+    VC("k32_cvt_256x320", 1, 16, 20, 0), VC("k512_cvtb_256x256", 16, 16, 16, 1), VC("k256_cvt_256x256", 8, 16, 16, 0),
+    VC("k512_cvtb_256x320", 16, 16, 20, 1), VC("k512_cvt_256x320", 16, 16, 20, 0),
 };
 
 static uint16_t toF16(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
