@@ -188,12 +188,16 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // pass 0's first entry words: an HBM round trip (they are read once per launch).  A short K loop does not cover it from
+    // the top of its last slice, so up to four slices request them before the loop and carry the registers through it.
+    constexpr bool kEarlyWords = KT <= 4;
+    if (kEarlyWords) loadWords(myList[0], wNext);
 
 #pragma unroll
     for (uint32_t t = 0; t < (uint32_t)KT; ++t) {
         if (t + 1u < (uint32_t)KT && !GEMM_LAB_SKIP(2))   // slice t + 1 -> the other stage
             gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds + ((t + 1u) & 1u) * stageBytes, bAt, wave, voffA, voffB, (t + 1u) * kGemmRowBytes);
-        if (t + 1u == (uint32_t)KT) loadWords(myList[0], wNext);   // pass 0's first words: an HBM round trip, hidden behind the last slice
+        if (!kEarlyWords && t + 1u == (uint32_t)KT) loadWords(myList[0], wNext);   // ... a long loop: behind its last slice
         const uint8_t* base = lds + (t & 1u) * stageBytes;
 #pragma unroll
         for (uint32_t s = 0; s < KSUB; ++s) {
@@ -389,10 +393,13 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (KT > 1 && !GEMM_LAB_SKIP(2)) gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds, bAtF, wave, voffA, voffB, kGemmRowBytes);
     __builtin_amdgcn_s_barrier();
+    // pass 0's first entry words (an HBM round trip): a loop of up to four slices requests them here and carries them through
+    constexpr bool kEarlyWords = KT <= 4;
+    if (kEarlyWords) loadWords(myList[0], wNext);
 
 #pragma unroll
     for (uint32_t t = 0; t < (uint32_t)KT; ++t) {
-        if (t + 1u == (uint32_t)KT) loadWords(myList[0], wNext);   // pass 0's first words: an HBM round trip, hidden behind the last slice
+        if (!kEarlyWords && t + 1u == (uint32_t)KT) loadWords(myList[0], wNext);
         const uint8_t* base = lds + hAt + (t & 1u) * hBytes;
         u32x4 bf[n];
 #pragma unroll
