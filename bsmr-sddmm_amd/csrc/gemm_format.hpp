@@ -38,9 +38,10 @@
 //                             every list is padded to a multiple of 4 words with kGemmNoEntry
 //   words     [u32]           one per stored dense entry, lists ordered by (row, position in P):
 //                             slab slot (12 bits) | row in the wave's rows (7) << 12 | offset (13) << 19
-//                             slab slot = ((tile in pass) * 64 + 16 (r >> 2) + c) * 4 + (r & 3) for row r, column c of a
-//                             16 x 16 tile (the MFMA accumulator layout: lane 16 (r >> 2) + c, register r & 3); tile t of a
-//                             wave = (row tile) * n + (column tile), pass t / 16, tile in pass t % 16
+//                             slab slot = gemmSlabSlot(tile in pass, r, c) for row r, column c of a 16 x 16 tile (the MFMA
+//                             accumulator layout: lane 16 (r >> 2) + c, register r & 3; a register of the 64 lanes is one
+//                             run of 256 bytes in the slab); tile t of a wave = (row tile) * n + (column tile), pass
+//                             t / 16, tile in pass t % 16
 //                             offset = CSR index - rowStart of its row (< 8191: sorted CSR rows give < TN)
 // An entry is listed iff the RPHM (after the plan's own promotion / folding) has it in a dense block: the dense / sparse
 // assignment of every nnz is unchanged.  Rows need not be sorted, but one row's entries inside one macro-tile must lie
@@ -57,6 +58,13 @@
 namespace bsmr {
 
 constexpr uint32_t kGemmWavesM = 2, kGemmWavesN = 4, kGemmWaves = kGemmWavesM * kGemmWavesN;
+// where the epilogue's dump leaves accumulator cell (r, c) of the pass's tile tp, in floats from the wave's slab: register
+// r & 3 of lane 16 (r >> 2) + c; one register of all 64 lanes = 256 contiguous bytes (one ds_write_addtid_b32)
+#if defined(BSMR_GEMM_DUMP_B128)   // lab: the dump as one ds_write_b128 per tile and lane
+__host__ __device__ constexpr uint32_t gemmSlabSlot(uint32_t tp, uint32_t r, uint32_t c) { return (tp * 64u + (r >> 2) * 16u + c) * 4u + (r & 3u); }
+#else
+__host__ __device__ constexpr uint32_t gemmSlabSlot(uint32_t tp, uint32_t r, uint32_t c) { return tp * 256u + (r & 3u) * 64u + (r >> 2) * 16u + c; }
+#endif
 constexpr uint32_t kGemmPassTiles = 16;        // 16 x 16 tiles of a wave per slab pass (16 KiB of fp32 per wave)
 constexpr uint32_t kGemmNoEntry = 0xFFFFFFFFu; // padding word (offset 8191 is never a real offset)
 constexpr uint32_t kGemmMaxOffset = 8191u;
@@ -206,7 +214,7 @@ inline int packGemm(const HostDense& hd, uint32_t PM, uint32_t NB, GemmFormatHos
         const uint32_t r = place & 15u, c = slotCol & 15u;
         item = itemOf[(size_t)g * S + s];
         list = (wm * kGemmWavesN + wn) * Q + q;
-        slot = (tp * 64 + (r >> 2) * 16 + c) * 4 + (r & 3u);
+        slot = gemmSlabSlot(tp, r, c);
         rowInWave = tm * 16 + r;
         rowInTile = pj * 16 + r;
     };

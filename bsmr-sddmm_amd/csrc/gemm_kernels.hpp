@@ -59,11 +59,22 @@ constexpr uint32_t gemmRingBytes(int PM, int NB) {
 constexpr size_t gemmLdsBytes(int PM, int NB) { return gemmRingBytes(PM, NB) + (size_t)PM * 16u * 4u; }
 
 #if defined(BSMR_GEMM_LAB)
-#define GEMM_LAB_ARG , uint32_t labSkip   /* bit 0 MFMAs, 1 fragment reads (denseGemmCvt: the rounding step), 2 DMAs, 3 slab writes, 4 entry loads, 5 stores, 6 denseGemmCvt's fragment reads */
+// labSkip: bit 0 MFMAs, 1 fragment reads (denseGemmCvt: the rounding step), 2 DMAs, 3 slab writes, 4 entry loads, 5 stores,
+// 6 denseGemmCvt's fragment reads.  labStamps (may be null): per (workgroup, wave) eight readings of the 100 MHz clock -
+// 0 entry, 1 first stage requested, 2 own share of it landed, 3 first barrier passed, 4 K loop left, 5 + q pass q done.
+#define GEMM_LAB_ARG , uint32_t labSkip, unsigned long long* labStamps
 #define GEMM_LAB_SKIP(bit) (labSkip & (1u << (bit)))
+#define GEMM_LAB_STAMPS unsigned long long labStamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GEMM_LAB_STAMP(i) labStamp[i] = __builtin_amdgcn_s_memrealtime()
+#define GEMM_LAB_STAMPS_OUT                                                                              \
+    if (labStamps && lane == 0)                                                                          \
+        for (uint32_t i = 0; i < 8u; ++i) labStamps[((size_t)blockIdx.x * kGemmWaves + wave) * 8u + i] = labStamp[i]
 #else
 #define GEMM_LAB_ARG
 #define GEMM_LAB_SKIP(bit) false
+#define GEMM_LAB_STAMPS
+#define GEMM_LAB_STAMP(i)
+#define GEMM_LAB_STAMPS_OUT
 #endif
 
 // lab builds: a value that feeds a part left out stays computed (the host pass does not know the register constraint)
@@ -73,6 +84,35 @@ __device__ __forceinline__ void gemmKeep(const u32x4& x) {
 #else
     (void)x;
 #endif
+}
+
+// The epilogue's dump of one accumulator tile into the wave's slab (gemmSlabSlot: register j of the 64 lanes = the 256 bytes at
+// 256 j).  ds_write_addtid_b32 stores 4 bytes per lane at M0[15:0] + offset + 4 lane in 2 cycles per wave-instruction - four of
+// them 8 cycles where one ds_write_b128 takes 13 (MI355X_MICROARCH.md, LDS): the slab passes are bound by exactly this
+// transfer.  M0 holds 16 bits: tiles at 64 KiB and above (the slabs of waves 4 - 7) are reached through the immediate
+// (kGemmDumpHigh + 256 j <= 65532).  One wait state between the write of M0 and its use (the assembler does not see into
+// the statement); LDS operations of a wave complete in order, so the entry reads that follow need no wait of their own.
+constexpr uint32_t kGemmDumpHigh = 64764u;
+__device__ __forceinline__ void gemmDumpTile(const f32x4& a, uint32_t tileAddr, bool high) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    if (!high)
+        asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
+                     "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768"
+                     ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "s"(tileAddr) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:64764\n\tds_write_addtid_b32 %1 offset:65020\n\t"
+                     "ds_write_addtid_b32 %2 offset:65276\n\tds_write_addtid_b32 %3 offset:65532"
+                     ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "s"(tileAddr - kGemmDumpHigh) : "memory", "m0");
+#pragma clang diagnostic pop
+#else
+    (void)a; (void)tileAddr; (void)high;
+#endif
+}
+// LDS byte address of a pointer into the dynamic allocation
+__device__ __forceinline__ uint32_t gemmLdsAddress(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
 // This wave's share of one stage: ADMAS + BDMAS LDS-DMA instructions of 1 KiB (8 rows of 128 bytes), voff = the lane's
@@ -138,6 +178,8 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t wm = wave / kGemmWavesN, wn = wave % kGemmWavesN;
     const uint32_t r = lane & 15u, g = lane >> 4;
+    GEMM_LAB_STAMPS;
+    GEMM_LAB_STAMP(0);
 
     const uint8_t* Ab = static_cast<const uint8_t*>(Aop) + (size_t)blockIdx.y * batch.strideA * ESZ;
     const uint8_t* Bb = static_cast<const uint8_t*>(Bop) + (size_t)blockIdx.y * batch.strideB * ESZ;
@@ -160,6 +202,7 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
         voffA[j] = id * (K * ESZ) + (((lane & 7u) ^ (SRC32 ? gemmSwz32(row) : gemmSwz16(row))) << 4);
     }
     if (!GEMM_LAB_SKIP(2)) gemmStagePart<ADMAS>(Ab, aBytes, lds, wave, voffA, 0u);
+    GEMM_LAB_STAMP(1);
     // the macro-tile's table of first indices, one row per thread
     if (threadIdx.x < TM) reinterpret_cast<uint32_t*>(lds + rowTableAt)[threadIdx.x] = rowStart[(size_t)itemId * TM + threadIdx.x];
     // entry lists of this wave: words[myList[q] .. myList[q + 1]) is pass q's
@@ -187,7 +230,9 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
     uint32_t wNext[kGemmWordChunk];
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GEMM_LAB_STAMP(2);
     __builtin_amdgcn_s_barrier();
+    GEMM_LAB_STAMP(3);
     // pass 0's first entry words: an HBM round trip (they are read once per launch).  A short K loop does not cover it from
     // the top of its last slice, so up to four slices request them before the loop and carry the registers through it.
     constexpr bool kEarlyWords = KT <= 4;
@@ -235,10 +280,13 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
     }
 
     // ---- the sparse mask: slab passes over the wave's tiles
+    GEMM_LAB_STAMP(4);
     float* slab = reinterpret_cast<float*>(lds) + wave * (kGemmPassTiles * 256u);
+    const uint32_t slabAddr = __builtin_amdgcn_readfirstlane(gemmLdsAddress(slab));
     const uint32_t* rowTable = reinterpret_cast<const uint32_t*>(lds + rowTableAt) + wm * (TM / 2u);
 #pragma unroll
     for (uint32_t q = 0; q < Q; ++q) {
+#if defined(BSMR_GEMM_DUMP_B128)
         if (!GEMM_LAB_SKIP(3)) {
 #pragma unroll
             for (uint32_t tp = 0; tp < kGemmPassTiles; ++tp) {
@@ -246,6 +294,23 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
                 if (tIdx < m * n) *reinterpret_cast<f32x4*>(slab + (tp * 64u + lane) * 4u) = acc[tIdx / n][tIdx % n];
             }
         }
+#else
+        if (!GEMM_LAB_SKIP(3)) {
+            if (slabAddr < 0x10000u) {
+#pragma unroll
+                for (uint32_t tp = 0; tp < kGemmPassTiles; ++tp) {
+                    const uint32_t tIdx = q * kGemmPassTiles + tp;
+                    if (tIdx < m * n) gemmDumpTile(acc[tIdx / n][tIdx % n], slabAddr + tp * 1024u, false);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t tp = 0; tp < kGemmPassTiles; ++tp) {
+                    const uint32_t tIdx = q * kGemmPassTiles + tp;
+                    if (tIdx < m * n) gemmDumpTile(acc[tIdx / n][tIdx % n], slabAddr + tp * 1024u, true);
+                }
+            }
+        }
+#endif
         const uint32_t first = myList[q], last = myList[q + 1u];
         uint32_t w[kGemmWordChunk];
 #pragma unroll
@@ -262,7 +327,9 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
                 }
             }
         }
+        GEMM_LAB_STAMP(5u + q);
     }
+    GEMM_LAB_STAMPS_OUT;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -321,6 +388,8 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t wm = wave / kGemmWavesN, wn = wave % kGemmWavesN;
     const uint32_t r = lane & 15u, g = lane >> 4;
+    GEMM_LAB_STAMPS;
+    GEMM_LAB_STAMP(0);
     const uint8_t* Ab = reinterpret_cast<const uint8_t*>(Aop) + (size_t)blockIdx.y * batch.strideA * 4u;
     const uint8_t* Bb = reinterpret_cast<const uint8_t*>(Bop) + (size_t)blockIdx.y * batch.strideB * 4u;
     P += (size_t)blockIdx.y * batch.strideP;
@@ -337,6 +406,7 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
     for (uint32_t j = 0; j < ADMAS; ++j)
         voffA[j] = gemmRowOfLane(panelRows + (size_t)group * TM + 8u * (wave * ADMAS + j), lane >> 3) * (K * 4u) + (piece << 4);
     if (!GEMM_LAB_SKIP(2)) gemmStagePart<ADMAS>(Ab, aBytes, lds, wave, voffA, 0u);
+    GEMM_LAB_STAMP(1);
     if (threadIdx.x < TM) reinterpret_cast<uint32_t*>(lds + rowTableAt)[threadIdx.x] = rowStart[(size_t)itemId * TM + threadIdx.x];
     uint32_t myList[Q + 1];
 #pragma unroll
@@ -389,10 +459,12 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
 
     // slice 0: landed (my chunks), rounded into H[0], slice 1 requested, H[0] published
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GEMM_LAB_STAMP(2);
     roundChunks(0u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (KT > 1 && !GEMM_LAB_SKIP(2)) gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds, bAtF, wave, voffA, voffB, kGemmRowBytes);
     __builtin_amdgcn_s_barrier();
+    GEMM_LAB_STAMP(3);
     // pass 0's first entry words (an HBM round trip): a loop of up to four slices requests them here and carries them through
     constexpr bool kEarlyWords = KT <= 4;
     if (kEarlyWords) loadWords(myList[0], wNext);
@@ -431,10 +503,13 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
     }
 
     // ---- the sparse mask: slab passes over the wave's tiles (as denseGemm)
+    GEMM_LAB_STAMP(4);
     float* slab = reinterpret_cast<float*>(lds) + wave * (kGemmPassTiles * 256u);
+    const uint32_t slabAddr = __builtin_amdgcn_readfirstlane(gemmLdsAddress(slab));
     const uint32_t* rowTable = reinterpret_cast<const uint32_t*>(lds + rowTableAt) + wm * (TM / 2u);
 #pragma unroll
     for (uint32_t q = 0; q < Q; ++q) {
+#if defined(BSMR_GEMM_DUMP_B128)
         if (!GEMM_LAB_SKIP(3)) {
 #pragma unroll
             for (uint32_t tp = 0; tp < kGemmPassTiles; ++tp) {
@@ -442,6 +517,23 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
                 if (tIdx < m * n) *reinterpret_cast<f32x4*>(slab + (tp * 64u + lane) * 4u) = acc[tIdx / n][tIdx % n];
             }
         }
+#else
+        if (!GEMM_LAB_SKIP(3)) {
+            if (slabAddr < 0x10000u) {
+#pragma unroll
+                for (uint32_t tp = 0; tp < kGemmPassTiles; ++tp) {
+                    const uint32_t tIdx = q * kGemmPassTiles + tp;
+                    if (tIdx < m * n) gemmDumpTile(acc[tIdx / n][tIdx % n], slabAddr + tp * 1024u, false);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t tp = 0; tp < kGemmPassTiles; ++tp) {
+                    const uint32_t tIdx = q * kGemmPassTiles + tp;
+                    if (tIdx < m * n) gemmDumpTile(acc[tIdx / n][tIdx % n], slabAddr + tp * 1024u, true);
+                }
+            }
+        }
+#endif
         const uint32_t first = myList[q], last = myList[q + 1u];
         uint32_t w[kGemmWordChunk];
 #pragma unroll
@@ -458,7 +550,9 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
                 }
             }
         }
+        GEMM_LAB_STAMP(5u + q);
     }
+    GEMM_LAB_STAMPS_OUT;
 }
 
 }  // namespace bsmr

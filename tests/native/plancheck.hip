@@ -353,7 +353,7 @@ extern "C" int plancheck_gemm(const bsmr_rphm_desc* d, uint32_t PM, uint32_t NB,
                     }
                     if (padding) return 11;
                     const uint32_t slot = word & 4095u, rw = (word >> 12) & 127u, off = word >> 19;
-                    const uint32_t tp = slot >> 8, lane = (slot >> 2) & 63u, reg = slot & 3u;
+                    const uint32_t tp = slot >> 8, reg = (slot >> 6) & 3u, lane = slot & 63u;   // gemmSlabSlot
                     const uint32_t t = q * bsmr::kGemmPassTiles + tp;
                     if (t >= m * n || rw >= m * 16) return 12;
                     const uint32_t tm = t / n, tn = t % n, r = rw % 16;

@@ -28,8 +28,8 @@
 using bsmr::GemmItem;
 #ifdef BSMR_GEMM_LAB
 typedef void (*Kernel)(const void*, const void*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, const GemmItem*, const uint32_t*,
-                       const uint32_t*, const uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, bsmr::Batch, uint32_t);
-#define LAB_ARGS , skip
+                       const uint32_t*, const uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, bsmr::Batch, uint32_t, unsigned long long*);
+#define LAB_ARGS , skip, stampsArg
 #else
 typedef void (*Kernel)(const void*, const void*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, const GemmItem*, const uint32_t*,
                        const uint32_t*, const uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, bsmr::Batch);
@@ -167,6 +167,8 @@ int main(int argc, char** argv) {
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(v->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const bsmr::Batch batch{0, 0, 0, 1};
     const uint32_t full = f.fullGrid && !getenv("GEMM_ITEMS") ? 1u : 0u;   // GEMM_ITEMS=1: take the places from the item records
+    unsigned long long* stampsArg = nullptr;   // lab builds: where one launch leaves its clock readings
+    (void)stampsArg;
     auto launch = [&]() {
         hipLaunchKernelGGL(v->kernel, dim3((uint32_t)f.items.size()), dim3(512), lds, nullptr, dA, dB, (uint32_t)(A16.size() * esz),
                            (uint32_t)(B16.size() * esz), dRows, dColOf, dItems, dRowStart, dLists, dWords, dP, N, f.numGroups, f.numStrips, full, batch LAB_ARGS);
@@ -211,6 +213,46 @@ int main(int argc, char** argv) {
         best = std::min(best, ms / iters);
         sum += ms / iters;
     }
+#ifdef BSMR_GEMM_LAB
+    {   // one launch with clock readings (100 MHz): where the waves are when, relative to the first wave's entry
+        const size_t count = f.items.size() * 8 * 8;
+        unsigned long long* dStamps;
+        CHECK(hipMalloc(&dStamps, count * 8));
+        CHECK(hipMemset(dStamps, 0, count * 8));
+        for (int i = 0; i < 10; ++i) launch();
+        stampsArg = dStamps;
+        launch();
+        stampsArg = nullptr;
+        CHECK(hipDeviceSynchronize());
+        std::vector<unsigned long long> st(count);
+        CHECK(hipMemcpy(st.data(), dStamps, count * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (size_t w = 0; w < count / 8; ++w) t0 = std::min(t0, st[w * 8]);
+        static const char* kNames[8] = {"entry", "first stage requested", "own share landed", "first barrier passed", "K loop left", "pass 0 done", "pass 1 done", "pass 2 done"};
+        printf("  clock readings over %zu waves, us after the first wave's entry (min / mean / max):\n", count / 8);
+        for (int i = 0; i < 8; ++i) {
+            double lo = 1e30, hi = 0, sum = 0;
+            size_t seen = 0;
+            for (size_t w = 0; w < count / 8; ++w) {
+                if (!st[w * 8 + i]) continue;
+                const double us = (double)(st[w * 8 + i] - t0) * 0.01;
+                lo = std::min(lo, us); hi = std::max(hi, us); sum += us; ++seen;
+            }
+            if (seen) printf("    %-22s %6.2f %6.2f %6.2f\n", kNames[i], lo, sum / seen, hi);
+        }
+        // the workgroups' last readings, sorted: how the launch drains
+        std::vector<double> ends;
+        for (size_t g = 0; g < f.items.size(); ++g) {
+            unsigned long long e = 0;
+            for (size_t w = 0; w < 8; ++w)
+                for (int i = 4; i < 8; ++i) e = std::max(e, st[(g * 8 + w) * 8 + i]);
+            ends.push_back((double)(e - t0) * 0.01);
+        }
+        std::sort(ends.begin(), ends.end());
+        printf("    workgroups done: 10 %% %.2f, 50 %% %.2f, 90 %% %.2f, 99 %% %.2f, last %.2f\n", ends[ends.size() / 10], ends[ends.size() / 2],
+               ends[ends.size() * 9 / 10], ends[ends.size() * 99 / 100], ends.back());
+    }
+#endif
     const double flops = 2.0 * (double)f.numTiles * 256.0 * K;
     printf("%s M=%u N=%u nnz=%u items=%zu tiles=%llu words=%zu lds=%zu skip=0x%x: %.2f us best, %.2f us mean; executed %.1f TFLOP/s, useful %.1f; "
            "unwritten %llu, bad %llu, max rel %.2e\n",

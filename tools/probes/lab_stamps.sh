@@ -1,0 +1,10 @@
+mkdir -p gpurun_out/lab1
+P=tools/probes/gemm_probe_lab
+(
+timeout -k 10 120 $P 1500 12419 0.04 k128_cvt_256x320 200 0 &&
+timeout -k 10 120 $P 1500 12419 0.04 k128_h_256x320 200 0 &&
+timeout -k 10 120 $P 1500 12419 0.04 k128_cvt_128x320 200 0 &&
+timeout -k 10 120 $P 4096 4096 0.1 k512_b_256x256 200 0 &&
+timeout -k 10 120 $P 4096 4096 0.1 k64_h_256x256 200 0
+) > gpurun_out/lab1/stamps.txt 2>&1
+cat gpurun_out/lab1/stamps.txt
