@@ -244,31 +244,173 @@ int useDevice(int device) {
     return BSMR_OK;
 }
 
+int copyPageable(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
+
 template <typename T>
 int upload(T*& dst, const std::vector<T>& src, uint64_t& bytes) {
     dst = nullptr;
     if (src.empty()) return BSMR_OK;
     const size_t n = src.size() * sizeof(T);
     if (!hipOk(hipMalloc(reinterpret_cast<void**>(&dst), n), "hipMalloc(plan)")) return BSMR_ERR_OOM;
-    BSMR_HIP(hipMemcpy(dst, src.data(), n, hipMemcpyHostToDevice));
+    if (const int st = copyPageable(dst, src.data(), n, hipMemcpyHostToDevice, nullptr)) return st;
     bytes += n;
     return BSMR_OK;
 }
 
+// BSMR_PLAN_TIMING=1: the stages of a plan's construction on stderr, milliseconds each (the device is synchronised at every
+// mark, so the stages of an asynchronous chain are attributed; off, a mark costs one load)
+struct StageTrace {
+    const bool on = std::getenv("BSMR_PLAN_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void mark(const char* name) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[plan] %-34s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
+// Scratch arrays of one construction, freed together.  Carved from chunks of at least 32 MiB: a plan's device road asks for
+// some forty arrays, and forty hipMalloc / hipFree pairs (each free waits for the device) were 1.5 ms of the 10 ms it takes
+// for the nips-like plan.
 struct DeviceBuffers {
-    std::vector<void*> ptrs;
+    static constexpr size_t kChunk = 32u << 20;
+    std::vector<void*> ptrs;   // the chunks
+    uint8_t* cursor = nullptr;
+    size_t room = 0;
     ~DeviceBuffers() {
         for (void* p : ptrs) (void)hipFree(p);
     }
     template <typename T>
     bool alloc(T** out, size_t count, const char* what) {
-        void* p = nullptr;
-        if (!hipOk(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)), what)) return false;
-        ptrs.push_back(p);
-        *out = static_cast<T*>(p);
+        const size_t bytes = (std::max<size_t>(count * sizeof(T), 16) + 255u) & ~(size_t)255u;
+        if (bytes > room) {
+            const size_t chunk = std::max(bytes, kChunk);
+            void* p = nullptr;
+            if (hipMalloc(&p, chunk) != hipSuccess) {
+                (void)hipGetLastError();
+                // (a device nearly full: the exact size, as before)
+                if (chunk == bytes || !hipOk(hipMalloc(&p, bytes), what)) return false;
+                ptrs.push_back(p);
+                *out = static_cast<T*>(p);
+                return true;
+            }
+            ptrs.push_back(p);
+            cursor = static_cast<uint8_t*>(p);
+            room = chunk;
+        }
+        *out = reinterpret_cast<T*>(cursor);
+        cursor += bytes;
+        room -= bytes;
         return true;
     }
 };
+
+// Copies between pageable host memory and the device through a small ring of pinned buffers: the runtime's own pageable
+// path stages through one buffer at 3.5 GB/s (22 MB of block values = 6.5 ms of the nips-like plan's 12); here the copy of
+// chunk i + 1 into its pinned buffer runs beside the DMA of chunk i.  Synchronous for the caller (the last DMA is waited for).
+struct PinnedRing {
+    static constexpr size_t kBuffers = 4, kBytes = 1u << 20;
+    uint8_t* buf[kBuffers] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t done[kBuffers] = {nullptr, nullptr, nullptr, nullptr};
+    bool ok = false;
+    PinnedRing() {
+        for (size_t i = 0; i < kBuffers; ++i)
+            if (hipHostMalloc(reinterpret_cast<void**>(&buf[i]), kBytes, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                return;
+            }
+        ok = true;
+    }
+    ~PinnedRing() {
+        for (size_t i = 0; i < kBuffers; ++i) {
+            if (done[i]) (void)hipEventDestroy(done[i]);
+            if (buf[i]) (void)hipHostFree(buf[i]);
+        }
+    }
+    PinnedRing(const PinnedRing&) = delete;
+    PinnedRing& operator=(const PinnedRing&) = delete;
+};
+int copyPageable(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+    if (bytes == 0) return BSMR_OK;
+    // (from 64 KiB: the runtime's own pageable path costs its first caller in a process ~5 ms of set-up; a plan's copies
+    // below that size do not take it)
+    if (bytes < (64u << 10)) {
+        BSMR_HIP(hipMemcpyAsync(dst, src, bytes, kind, s));
+        BSMR_HIP(hipStreamSynchronize(s));
+        return BSMR_OK;
+    }
+    StageTrace trace;
+    // rings are kept for the life of the process, per device (their events belong to one)
+    static std::mutex poolLock;
+    static std::map<int, std::vector<PinnedRing*>> pool;
+    int device = 0;
+    BSMR_HIP(hipGetDevice(&device));
+    PinnedRing* held = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(poolLock);
+        std::vector<PinnedRing*>& mine = pool[device];
+        if (!mine.empty()) {
+            held = mine.back();
+            mine.pop_back();
+        }
+    }
+    if (!held) held = new (std::nothrow) PinnedRing;
+    struct Return {
+        PinnedRing* r;
+        int device;
+        ~Return() {
+            if (!r) return;
+            if (!r->ok) {
+                delete r;
+                return;
+            }
+            std::lock_guard<std::mutex> lock(poolLock);
+            pool[device].push_back(r);
+        }
+    } giveBack{held, device};
+    if (!held || !held->ok) {
+        BSMR_HIP(hipMemcpyAsync(dst, src, bytes, kind, s));
+        BSMR_HIP(hipStreamSynchronize(s));
+        return BSMR_OK;
+    }
+    PinnedRing& ring = *held;
+    trace.mark("  pageable copy: ring");
+    const size_t chunks = (bytes + PinnedRing::kBytes - 1) / PinnedRing::kBytes;
+    const uint8_t* from = static_cast<const uint8_t*>(src);
+    uint8_t* to = static_cast<uint8_t*>(dst);
+    if (kind == hipMemcpyHostToDevice) {
+        for (size_t c = 0; c < chunks; ++c) {
+            const size_t i = c % PinnedRing::kBuffers, at = c * PinnedRing::kBytes, n = std::min(PinnedRing::kBytes, bytes - at);
+            if (c >= PinnedRing::kBuffers) BSMR_HIP(hipEventSynchronize(ring.done[i]));
+            std::memcpy(ring.buf[i], from + at, n);
+            BSMR_HIP(hipMemcpyAsync(to + at, ring.buf[i], n, hipMemcpyHostToDevice, s));
+            BSMR_HIP(hipEventRecord(ring.done[i], s));
+        }
+        BSMR_HIP(hipStreamSynchronize(s));
+    } else {
+        // device -> host: chunk c's DMA is requested kBuffers - 1 chunks ahead of the copy out of its pinned buffer
+        auto request = [&](size_t c) -> int {
+            const size_t i = c % PinnedRing::kBuffers, at = c * PinnedRing::kBytes, n = std::min(PinnedRing::kBytes, bytes - at);
+            BSMR_HIP(hipMemcpyAsync(ring.buf[i], from + at, n, hipMemcpyDeviceToHost, s));
+            BSMR_HIP(hipEventRecord(ring.done[i], s));
+            return BSMR_OK;
+        };
+        for (size_t c = 0; c < std::min(chunks, PinnedRing::kBuffers - 1); ++c)
+            if (const int st = request(c)) return st;
+        for (size_t c = 0; c < chunks; ++c) {
+            const size_t i = c % PinnedRing::kBuffers, at = c * PinnedRing::kBytes, n = std::min(PinnedRing::kBytes, bytes - at);
+            if (c + PinnedRing::kBuffers - 1 < chunks)
+                if (const int st = request(c + PinnedRing::kBuffers - 1)) return st;
+            BSMR_HIP(hipEventSynchronize(ring.done[i]));
+            std::memcpy(to + at, ring.buf[i], n);
+        }
+    }
+    trace.mark("  pageable copy: chunks");
+    return BSMR_OK;
+}
 
 int envInt(const char* name, int fallback) {
     const char* v = std::getenv(name);
@@ -534,11 +676,15 @@ int promoteOnDevice(const bsmr_rphm_desc& in, uint32_t minAverage, uint64_t minE
 // The default dense layout (one panel per group, blocks in column order, window offsets) from the RPHM arrays, on the
 // current device.  BSMR_OK: `f` is complete; kPackOnHost: nothing is kept, the host packer has to do this plan.
 int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, const std::vector<uint32_t>& panelRows, DenseFormat& f,
-                      uint64_t& indexBytes, DevicePackResult& r, uint32_t* residentCols = nullptr, uint32_t* residentValues = nullptr) {
+                      uint64_t& indexBytes, DevicePackResult& r, uint32_t* residentCols = nullptr, uint32_t* residentValues = nullptr,
+                      bsmr::HostDense* collect = nullptr) {
+    // collect != null: the plan keeps the dense entries as per-panel (column, row) lists for the formats of the other dense
+    // engines (bsmr::collectDense on the host road); here they are written from the packed blocks and fetched, 9 bytes an entry
     const uint32_t P = d->num_row_panels;
     const uint64_t oldBlocks = d->block_offsets[P], slots = oldBlocks * 16;
     if (oldBlocks == 0 || slots > 0x7FFFFFFFull || P == 0) return kPackOnHost;
     hipStream_t s = nullptr;
+    StageTrace trace;
     DeviceBuffers dev;   // scratch, freed on return
     uint32_t *dCols, *dOffsets, *dValues, *dSlots, *dSlotsAlt, *dPanelCols, *dPanelBlocks, *dFirstBlock, *dFlags, *dMaxItem;
     uint64_t *dKeys, *dKeysAlt;
@@ -554,9 +700,13 @@ int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, con
         !dev.alloc(&dPanelBlocks, (size_t)P + 1, "hipMalloc") || !dev.alloc(&dFirstBlock, (size_t)P + 1, "hipMalloc") ||
         !dev.alloc(&dFlags, 1, "hipMalloc") || !dev.alloc(&dMaxItem, 1, "hipMalloc") || !dev.alloc(&dCounters, 2, "hipMalloc"))
         return BSMR_ERR_OOM;
-    if (!resident) BSMR_HIP(hipMemcpyAsync(dCols, d->dense_cols, slots * 4, hipMemcpyHostToDevice, s));
+    trace.mark("device packer: scratch");
+    if (!resident)
+        if (const int st = copyPageable(dCols, d->dense_cols, slots * 4, hipMemcpyHostToDevice, s)) return st;
     BSMR_HIP(hipMemcpyAsync(dOffsets, d->block_offsets, ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
-    if (!resident) BSMR_HIP(hipMemcpyAsync(dValues, d->block_values, oldBlocks * 1024, hipMemcpyHostToDevice, s));
+    if (!resident)
+        if (const int st = copyPageable(dValues, d->block_values, oldBlocks * 1024, hipMemcpyHostToDevice, s)) return st;
+    trace.mark("device packer: upload arrays");
     BSMR_HIP(hipMemsetAsync(dFlags, 0, 4, s));
     BSMR_HIP(hipMemsetAsync(dMaxItem, 0, 4, s));
     BSMR_HIP(hipMemsetAsync(dCounters, 0, 16, s));
@@ -589,6 +739,7 @@ int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, con
     BSMR_HIP(hipMemcpyAsync(&numBlocks, dFirstBlock + P, 4, hipMemcpyDeviceToHost, s));
     BSMR_HIP(hipMemcpyAsync(&flags, dFlags, 4, hipMemcpyDeviceToHost, s));
     BSMR_HIP(hipStreamSynchronize(s));
+    trace.mark("device packer: column sort");
     if (flags & 1u) return BSMR_ERR_BAD_PLAN;
     if ((flags & 2u) || numBlocks == 0) return kPackOnHost;
     r.unionColumns = 0;
@@ -597,6 +748,9 @@ int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, con
 
     // blocks: columns, destinations in accumulator order, per-row ranges
     uint32_t *dPanelOfBlock, *dAbs, *dRowLo, *dRowHi, *dIsFirst, *dCountAtFirst, *dLoAtFirst, *dHiAtFirst, *dItemBefore;
+    uint32_t *dBlockCount = nullptr, *dBlockStart = nullptr;
+    if (collect && (!dev.alloc(&dBlockCount, (size_t)numBlocks + 1, "hipMalloc") || !dev.alloc(&dBlockStart, (size_t)numBlocks + 1, "hipMalloc")))
+        return BSMR_ERR_OOM;
     if (!dev.alloc(&dPanelOfBlock, numBlocks, "hipMalloc") || !dev.alloc(&dAbs, (size_t)numBlocks * 256, "hipMalloc") ||
         !dev.alloc(&dRowLo, (size_t)numBlocks * 16, "hipMalloc") || !dev.alloc(&dRowHi, (size_t)numBlocks * 16, "hipMalloc") ||
         !dev.alloc(&dIsFirst, numBlocks, "hipMalloc") || !dev.alloc(&dCountAtFirst, numBlocks, "hipMalloc") ||
@@ -625,7 +779,7 @@ int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, con
     hipLaunchKernelGGL(bsmr::packPanelOfBlock, dim3(P), dim3(256), 0, s, dFirstBlock, P, dPanelOfBlock);
     hipLaunchKernelGGL(bsmr::packBlocks, dim3((numBlocks + 3) / 4), dim3(256), 0, s, sKeys, sSlots, dOffsets, dValues, dPanelCols,
                        dFirstBlock, dPanelOfBlock, numBlocks, d->nnz, out.blockCols, dAbs, dRowLo, dRowHi, out.blockMask, dCounters,
-                       dFlags);
+                       dFlags, dBlockCount);
     const uint32_t perItem = (uint32_t)std::max(1, opt.blocksPerItem);
     hipLaunchKernelGGL(bsmr::packItems, dim3(P), dim3(64), 0, s, dFirstBlock, dRowLo, dRowHi, perItem, dIsFirst, dCountAtFirst,
                        dLoAtFirst, dHiAtFirst, dFlags, dMaxItem);
@@ -647,11 +801,54 @@ int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, con
     BSMR_HIP(hipMemcpyAsync(&out.maxItemBlocks, dMaxItem, 4, hipMemcpyDeviceToHost, s));
     BSMR_HIP(hipMemcpyAsync(counters, dCounters, 16, hipMemcpyDeviceToHost, s));
     BSMR_HIP(hipStreamSynchronize(s));
+    trace.mark("device packer: blocks + items");
     if (flags & 1u) return BSMR_ERR_BAD_PLAN;
     if (flags & 2u) return kPackOnHost;
     const uint32_t numItems = before + last;
     r.numDenseEntries = counters[0];
     r.numTiles = counters[1];
+    uint32_t* dListCol = nullptr;
+    uint32_t* dListIdx = nullptr;
+    uint8_t* dListRow = nullptr;
+    std::vector<uint32_t> listStart;   // [numBlocks + 1] first entry of every block, firstBlock: [P + 1] first block of every panel
+    std::vector<uint32_t> firstBlock;
+    if (collect) {
+        const uint64_t total = counters[0];
+        if (total > 0xFFFFFFFFull) return kPackOnHost;
+        size_t need2 = 0;
+        BSMR_HIP(hipMemsetAsync(dBlockCount + numBlocks, 0, 4, s));
+        BSMR_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need2, dBlockCount, dBlockStart, (int)numBlocks + 1, s));
+        uint8_t* dTempC = dTemp;
+        if (need2 > tempBytes) {
+            if (!dev.alloc(&dTempC, need2 + 256, "hipMalloc(scan scratch)")) return BSMR_ERR_OOM;
+        } else {
+            need2 = tempBytes;
+        }
+        BSMR_HIP(hipcub::DeviceScan::ExclusiveSum(dTempC, need2, dBlockCount, dBlockStart, (int)numBlocks + 1, s));
+        if (!dev.alloc(&dListCol, (size_t)total + 1, "hipMalloc") || !dev.alloc(&dListIdx, (size_t)total + 1, "hipMalloc") ||
+            !dev.alloc(&dListRow, (size_t)total + 1, "hipMalloc"))
+            return BSMR_ERR_OOM;
+        hipLaunchKernelGGL(bsmr::collectEmit, dim3((numBlocks + 3) / 4), dim3(256), 0, s, dAbs, out.blockCols, dBlockStart, numBlocks, dListCol,
+                           dListRow, dListIdx);
+        BSMR_HIP(hipGetLastError());
+        collect->M = d->M; collect->N = d->N; collect->nnz = d->nnz; collect->numPanels = P;
+        collect->panelRows = panelRows;
+        collect->col.resize(total);
+        collect->idx.resize(total);
+        collect->row.resize(total);
+        listStart.resize((size_t)numBlocks + 1);
+        firstBlock.resize((size_t)P + 1);
+        BSMR_HIP(hipMemcpyAsync(listStart.data(), dBlockStart, ((size_t)numBlocks + 1) * 4, hipMemcpyDeviceToHost, s));
+        BSMR_HIP(hipMemcpyAsync(firstBlock.data(), dFirstBlock, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, s));
+        if (total) {
+            int cs = copyPageable(collect->col.data(), dListCol, total * 4, hipMemcpyDeviceToHost, s);
+            if (cs == BSMR_OK) cs = copyPageable(collect->idx.data(), dListIdx, total * 4, hipMemcpyDeviceToHost, s);
+            if (cs == BSMR_OK) cs = copyPageable(collect->row.data(), dListRow, total, hipMemcpyDeviceToHost, s);
+            if (cs != BSMR_OK) return cs;
+        }
+        // (waited for with the items' flags below; the panels' offsets follow there)
+        trace.mark("device packer: entry lists");
+    }
 
     // items: records, windows, destinations, launch order
     bsmr::DenseItem* dItems0;
@@ -688,6 +885,14 @@ int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, con
     BSMR_HIP(hipGetLastError());
     BSMR_HIP(hipMemcpyAsync(&flags, dFlags, 4, hipMemcpyDeviceToHost, s));
     BSMR_HIP(hipStreamSynchronize(s));
+    trace.mark("device packer: encode + order");
+    if (collect) {
+        collect->offsets.assign((size_t)P + 1, 0);
+        for (uint32_t q = 0; q <= P; ++q) {
+            if (firstBlock[q] > numBlocks) return BSMR_ERR_BAD_PLAN;
+            collect->offsets[q] = listStart[firstBlock[q]];
+        }
+    }
     if (opt.maskTiles && !(flags & 4u)) {   // every tile row's offsets are consecutive: the 48-byte form
         (void)hipFree(out.tiles8);
         out.tiles8 = nullptr;
@@ -1817,15 +2022,13 @@ int bsmr_dev_free(void* ptr) {
 int bsmr_memcpy_h2d(void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return BSMR_OK;
     if (!dst || !src) return BSMR_ERR_INVALID_ARG;
-    BSMR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
-    return BSMR_OK;
+    return copyPageable(dst, src, bytes, hipMemcpyHostToDevice, nullptr);
 }
 
 int bsmr_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return BSMR_OK;
     if (!dst || !src) return BSMR_ERR_INVALID_ARG;
-    BSMR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
-    return BSMR_OK;
+    return copyPageable(dst, src, bytes, hipMemcpyDeviceToHost, nullptr);
 }
 
 int bsmr_dev_memset(void* dst, int value, size_t bytes) {
@@ -1990,14 +2193,16 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
                                      o.dense_engine == BSMR_ENGINE_TUNED || o.dense_engine == BSMR_ENGINE_SWEEP || o.dense_engine == BSMR_ENGINE_GEMM;
         const bool deviceLayout = o.dense_group <= 1 && o.column_order != 0 && o.output_mode != 0 && !o.force_tile32 && o.pack_on_device != 0 &&
                                   !envInt("BSMR_ITEM_ORDER", 0) && !envInt("BSMR_ITEM_SPAN", 0);
-        if (res && (hostDenseNeeded || !deviceLayout || o.promote_on_device == 0)) return kPackOnHost;
+        // (a plan that keeps the dense entry lists - hostDenseNeeded - gets them from the device packer, packDenseOnDevice's
+        // `collect`: it takes the device road like any other)
+        if (res && (!deviceLayout || o.promote_on_device == 0)) return kPackOnHost;
         // (device-resident arrays: the dense part as it is, its column lists and the residue fetched for the host-side steps)
         struct {
             std::vector<uint32_t> denseCols, sparseValues, sparseRows, sparseCols;
             bsmr_rphm_desc desc{};
         } fetched;
         bool denseResident = false;
-        if (offsetsOk && (numSparse || res) && !hostDenseNeeded && deviceLayout &&
+        if (offsetsOk && (numSparse || res) && deviceLayout &&
             (res || o.promote_on_device > 0 || (o.promote_on_device < 0 && numSparse >= (1u << 20)))) {
             bool applied = false;
             st = promoteOnDevice(*d, (uint32_t)std::max(0, o.promote_average), (uint64_t)std::max(0, o.promote_min_entries_k) * 1000ull, foldBelow,
@@ -2141,12 +2346,15 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
         opt.maskTiles = outputMode == 1 && (o.mask_tiles > 0 || (o.mask_tiles < 0 && (uint64_t)d->block_offsets[P] * 256ull > (32ull << 20)));
         const float rulesMs = msSince(tStart);
         const Clock::time_point tPack = Clock::now();
+        StageTrace trace;
+        trace.mark("(rules)");
         bsmr::PackedPlan pk;
         // the default dense layout is built by kernels from the uploaded RPHM arrays when the dense part is large enough
         // to repay the launches (csrc/pack_device.hpp); the residue and every other layout are packed on the host
         DenseFormat deviceFormat;
         uint64_t deviceFormatBytes = 0;
         bool packedOnDevice = false;
+        bsmr::HostDense collected;   // the dense entry lists, written by the device packer for the plans that keep them
         if (opt.group == 1 && opt.columnOrder && opt.staged && !opt.forceWideTiles &&
             !opt.itemOrder && !opt.itemSpan &&
             (o.pack_on_device > 0 || (o.pack_on_device < 0 && d->block_offsets[P] >= 4096))) {
@@ -2154,7 +2362,8 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
             if ((st = bsmr::packRows(d, pk)) != BSMR_OK) return st;
             st = packDenseOnDevice(d, opt, pk.panelRows, deviceFormat, deviceFormatBytes, r,
                                    promotedOnDevice ? onDevice.dCols : (denseResident ? res->denseCols : nullptr),
-                                   promotedOnDevice ? onDevice.dValues : (denseResident ? res->blockValues : nullptr));
+                                   promotedOnDevice ? onDevice.dValues : (denseResident ? res->blockValues : nullptr),
+                                   hostDenseNeeded ? &collected : nullptr);
             if (st == BSMR_OK) {
                 pk.H = 1;
                 pk.numGroups = P;
@@ -2163,10 +2372,12 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
                 pk.numBlocks = r.numBlocks;
                 pk.numTiles = r.numTiles;
                 pk.unionColumns = r.unionColumns;
+                trace.mark("device packer");
                 if ((st = bsmr::packResidue(d, opt, pk)) != BSMR_OK) {
                     dropDense(deviceFormat);
                     return st;
                 }
+                trace.mark("residue packer (host)");
                 packedOnDevice = true;
             } else if (st != kPackOnHost && st != BSMR_ERR_OOM) {   // (no room for the scratch arrays: the host packer needs none)
                 return st;
@@ -2185,6 +2396,7 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
             if (st != BSMR_OK) return st;
         }
         const float packMs = msSince(tPack);
+        trace.mark("packing (all of it)");
 
         bsmr_plan* p = new (std::nothrow) bsmr_plan;
         if (!p) {
@@ -2214,7 +2426,9 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
             p->tunable = o.dense_engine == BSMR_ENGINE_TUNED;
             p->useSweep = o.dense_engine == BSMR_ENGINE_SWEEP;
             p->useGemm = o.dense_engine == BSMR_ENGINE_GEMM;
-            if ((p->useTiles || p->tunable || p->useSweep || p->useGemm) && pk.numBlocks) {
+            if ((p->useTiles || p->tunable || p->useSweep || p->useGemm) && pk.numBlocks && packedOnDevice) {
+                p->hostDense = std::move(collected);
+            } else if ((p->useTiles || p->tunable || p->useSweep || p->useGemm) && pk.numBlocks) {
                 st = bsmr::collectDense(d, p->hostDense);
                 if (st != BSMR_OK) {
                     delete p;
@@ -2239,6 +2453,7 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
         p->convertBOnly = cvt < 0 && p->sparseLowp && pk.numBlocks == 0 && !pk.freeResidue && pk.numSparseEntries != 0 &&
                           o.b_only != 0;
 
+        trace.mark("dense entry lists");
         const Clock::time_point tUpload = Clock::now();
         if (packedOnDevice) {
             p->fmt[0] = deviceFormat;
@@ -2306,6 +2521,7 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
         }
         p->buildMs[3] = msSince(tSecond);
         p->buildMs[4] = msSince(tStart);
+        trace.mark("uploads + second format");
         if (o.k_hint > 0) {   // (the caller's arrays, not the promoted / folded ones the plan was packed from)
             const bsmr_rphm_desc& src = *given;
             auto keep = std::make_unique<bsmr_plan::Retained>();
@@ -2393,6 +2609,28 @@ int bsmr_plan_format_digest(const bsmr_plan* p, uint64_t out[13]) {
     out[10] = f.numTiles;
     out[11] = f.unionColumns;
     out[12] = f.tilesM ? 1 : 0;
+    return BSMR_OK;
+}
+
+int bsmr_plan_entry_lists_digest(const bsmr_plan* p, uint64_t out[5]) {
+    p = served(p);
+    if (!p || !out) return BSMR_ERR_INVALID_ARG;
+    const bsmr::HostDense& hd = p->hostDense;
+    auto fnv = [](const void* ptr, size_t bytes) {
+        uint64_t h = 0xcbf29ce484222325ull;
+        const uint8_t* b = static_cast<const uint8_t*>(ptr);
+        for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+        return h;
+    };
+    if (hd.offsets.empty()) {
+        for (int i = 0; i < 5; ++i) out[i] = 0;
+        return BSMR_OK;
+    }
+    out[0] = fnv(hd.offsets.data(), hd.offsets.size() * 8);
+    out[1] = fnv(hd.col.data(), hd.col.size() * 4);
+    out[2] = fnv(hd.row.data(), hd.row.size());
+    out[3] = fnv(hd.idx.data(), hd.idx.size() * 4);
+    out[4] = hd.entries();
     return BSMR_OK;
 }
 
@@ -3094,16 +3332,15 @@ int bsmr_sddmm_host(bsmr_plan* plan, uint32_t K, const float* A_host, const floa
         cleanup();
         return BSMR_ERR_OOM;
     }
-    if (!hipOk(hipMemcpy(A, A_host, aBytes, hipMemcpyHostToDevice), "h2d A") ||
-        !hipOk(hipMemcpy(B, B_host, bBytes, hipMemcpyHostToDevice), "h2d B") ||
+    if (copyPageable(A, A_host, aBytes, hipMemcpyHostToDevice, nullptr) != BSMR_OK ||
+        copyPageable(B, B_host, bBytes, hipMemcpyHostToDevice, nullptr) != BSMR_OK ||
         !hipOk(hipMemset(P, 0, std::max<size_t>(pBytes, 16)), "memset P")) {
         cleanup();
         return BSMR_ERR_HIP;
     }
     bsmr_timing t{};
     st = bsmr_sddmm_timed(plan, K, A, B, P, mode, nullptr, 1, iters, &t);
-    if (st == BSMR_OK && pBytes && !hipOk(hipMemcpy(P_host, P, pBytes, hipMemcpyDeviceToHost), "d2h P"))
-        st = BSMR_ERR_HIP;
+    if (st == BSMR_OK && pBytes) st = copyPageable(P_host, P, pBytes, hipMemcpyDeviceToHost, nullptr);
     if (st == BSMR_OK && ms_per_iter) *ms_per_iter = t.total_ms;
     cleanup();
     return st;

@@ -83,7 +83,7 @@ packBlocks(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ slots
            const uint32_t* __restrict__ firstBlock, const uint32_t* __restrict__ panelOfBlock, uint32_t numBlocks, uint32_t nnz,
            uint32_t* __restrict__ blockCols, uint32_t* __restrict__ absTiles, uint32_t* __restrict__ rowLo,
            uint32_t* __restrict__ rowHi, uint8_t* __restrict__ blockMask, unsigned long long* __restrict__ counters,
-           uint32_t* __restrict__ flags) {
+           uint32_t* __restrict__ flags, uint32_t* __restrict__ blockCount) {
     const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (b >= numBlocks) return;
     const uint32_t lane = threadIdx.x & 63u, cc = lane & 15u, rg = lane >> 4;
@@ -129,11 +129,53 @@ packBlocks(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ slots
     for (uint32_t m = 1; m < 64; m <<= 1) count += (uint32_t)__shfl_xor((int)count, (int)m);
     if (lane == 0) {
         blockMask[b] = count ? 1 : 0;
+        if (blockCount) blockCount[b] = count;   // (for collectEmit: plans that keep the entry lists)
         if (count) {
             atomicAdd(&counters[0], (unsigned long long)count);   // dense entries
             atomicAdd(&counters[1], 1ull);                        // non-empty tiles
         }
     }
+}
+
+// The dense entries as per-panel lists ordered by (column, row in panel) - HostDense of csrc/tile_format.hpp, what the
+// formats of the other dense engines are packed from - written from the new blocks, which already lie in column-id order:
+// one wave per block, entry (column cc, row r) of block b goes to blockStart[b] + (entries of the block in front of it in
+// (cc, r) order).  blockStart = exclusive scan of packBlocks' counts.
+__global__ void __launch_bounds__(256)
+collectEmit(const uint32_t* __restrict__ absTiles, const uint32_t* __restrict__ blockCols, const uint32_t* __restrict__ blockStart,
+            uint32_t numBlocks, uint32_t* __restrict__ outCol, uint8_t* __restrict__ outRow, uint32_t* __restrict__ outIdx) {
+    __shared__ uint32_t counts[4][64];
+    const uint32_t w = threadIdx.x >> 6, b = blockIdx.x * 4u + w;
+    if (b >= numBlocks) return;   // (whole waves leave: nothing below synchronises a workgroup)
+    const uint32_t lane = threadIdx.x & 63u, cc = lane & 15u, rg = lane >> 4;
+    const uint4 v4 = *reinterpret_cast<const uint4*>(absTiles + (uint64_t)b * 256u + lane * 4u);
+    const uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) mine += v[i] != kPackNone;
+    // lanes in list order: column major, then the row group
+    const uint32_t order = cc * 4u + rg;
+    counts[w][order] = mine;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t scan = counts[w][lane];
+#pragma unroll
+    for (uint32_t m = 1; m < 64; m <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)scan, (int)m);
+        if (lane >= m) scan += up;
+    }
+    __builtin_amdgcn_wave_barrier();
+    counts[w][lane] = scan;   // inclusive, by list order
+    __builtin_amdgcn_wave_barrier();
+    uint32_t at = blockStart[b] + counts[w][order] - mine;
+    const uint32_t col = blockCols[(uint64_t)b * 16u + cc];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i)
+        if (v[i] != kPackNone) {
+            outCol[at] = col;
+            outRow[at] = (uint8_t)(4u * rg + i);
+            outIdx[at] = v[i];
+            ++at;
+        }
 }
 
 // panelOfBlock for the new blocks

@@ -95,6 +95,41 @@ inline void parallelChunks(size_t n, size_t minPerWorker, F fn) {
         if (f) std::rethrow_exception(f);
 }
 
+// The same with chunks of about equal WEIGHT: prefix[i] = weight of [0, i) (n + 1 entries, ascending).  Panels of a clustered
+// matrix differ by two orders of magnitude in their block counts; equal panel counts would leave most workers idle.
+template <typename W, typename F>
+inline void parallelByWeight(size_t n, const W* prefix, uint64_t minPerWorker, F fn) {
+    const uint64_t total = n ? (uint64_t)prefix[n] - (uint64_t)prefix[0] : 0;
+    const size_t workers = std::max<size_t>(1, std::min<size_t>(packThreads(), (size_t)(total / std::max<uint64_t>(1, minPerWorker))));
+    if (workers <= 1) {
+        fn((size_t)0, n, (size_t)0);
+        return;
+    }
+    std::vector<size_t> cut(workers + 1, n);
+    cut[0] = 0;
+    for (size_t w = 1; w < workers; ++w) {
+        const uint64_t want = (uint64_t)prefix[0] + total * w / workers;
+        cut[w] = std::max<size_t>(cut[w - 1], (size_t)(std::lower_bound(prefix, prefix + n + 1, want, [](const W& a, uint64_t b) { return (uint64_t)a < b; }) - prefix));
+        cut[w] = std::min(cut[w], n);
+    }
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> failed(workers);
+    for (size_t w = 0; w < workers; ++w) {
+        const size_t b = cut[w], e = cut[w + 1];
+        if (b < e)
+            pool.emplace_back([=, &fn, &failed]() {
+                try {
+                    fn(b, e, w);
+                } catch (...) {
+                    failed[w] = std::current_exception();
+                }
+            });
+    }
+    for (std::thread& t : pool) t.join();
+    for (const std::exception_ptr& f : failed)
+        if (f) std::rethrow_exception(f);
+}
+
 struct PackOptions {
     int group = 1;            // panels per group: 1, 2 or 4
     int blocksPerItem = 32;   // dense blocks per workgroup item (upper bound)

@@ -85,7 +85,7 @@ inline int collectDense(const bsmr_rphm_desc* d, HostDense& out) {
     for (uint32_t p = 0; p < P; ++p)
         if (d->block_offsets[p + 1] < d->block_offsets[p]) return BSMR_ERR_BAD_PLAN;
     // (a sweep over all block values, 1 KiB per block: by all host threads - 22 MB for the nips-like plan, 5 of the 10 ms of this function)
-    parallelChunks(P, 4, [&](size_t p0, size_t p1, size_t) {
+    parallelByWeight(P, d->block_offsets, 512, [&](size_t p0, size_t p1, size_t) {
         for (size_t p = p0; p < p1; ++p) {
             uint64_t n = 0;
             for (uint64_t b = d->block_offsets[p]; b < d->block_offsets[p + 1]; ++b)
@@ -99,7 +99,7 @@ inline int collectDense(const bsmr_rphm_desc* d, HostDense& out) {
     out.idx.resize(total);
     out.row.resize(total);
     std::vector<uint8_t> bad(packThreads(), 0);
-    parallelChunks(P, 16, [&](size_t p0, size_t p1, size_t w) {
+    parallelByWeight(P, d->block_offsets, 512, [&](size_t p0, size_t p1, size_t w) {
         std::vector<uint64_t> keys;   // (column, row) | position: one plain sort
         std::vector<uint32_t> vals;
         for (size_t p = p0; p < p1; ++p) {
@@ -121,7 +121,7 @@ inline int collectDense(const bsmr_rphm_desc* d, HostDense& out) {
                     }
                 }
             if (keys.size() != out.offsets[p + 1] - out.offsets[p]) { bad[w] = 1; continue; }
-            std::sort(keys.begin(), keys.end());
+            if (!std::is_sorted(keys.begin(), keys.end())) std::sort(keys.begin(), keys.end());   // (blocks in column order arrive sorted)
             uint64_t at = out.offsets[p];
             for (const uint64_t k : keys) {
                 out.col[at] = (uint32_t)(k >> 36);

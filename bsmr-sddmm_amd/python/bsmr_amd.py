@@ -150,6 +150,7 @@ HIP_SYMBOLS = {
     "bsmr_plan_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
     "bsmr_plan_build_times": (C.c_int, [C.c_void_p, C.POINTER(PlanBuildMs)]),
     "bsmr_plan_format_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "bsmr_plan_entry_lists_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "bsmr_plan_tune": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                 C.POINTER(TuneReport)]),
     "bsmr_cluster_rows": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float,

@@ -328,6 +328,12 @@ int bsmr_plan_set_tuned(bsmr_plan *plan, uint32_t K, int mode, const bsmr_tuned_
  * items / blocks / tiles / union columns and 1 if the tiles are in the mask form (out[0..12]).  Two plans with equal
  * fingerprints launch identical dense work; used to check the device packer against the host packer. */
 int bsmr_plan_format_digest(const bsmr_plan *plan, uint64_t out[13]);
+/* Fingerprint of the dense entry lists a plan keeps for the formats of the tiles / shared / sweep / GEMM engines (plans
+ * created with one of these engines or BSMR_ENGINE_TUNED): FNV-1a of the panels' offsets, the entries' columns, rows in
+ * panel and CSR indices (out[0..3]), the number of entries (out[4]).  All zero for a plan that keeps none.  The lists are
+ * written by the device packer (csrc/pack_device.hpp: collectEmit) or by the host (csrc/tile_format.hpp: collectDense);
+ * used to check the one against the other. */
+int bsmr_plan_entry_lists_digest(const bsmr_plan *plan, uint64_t out[5]);
 /* Which dense format a call with inner dimension K uses (any out pointer may be NULL):
  * panels per group, MFMA tiles executed, B columns gathered.  For a plan whose engines were measured (bsmr_plan_tune)
  * the answer describes the engine of the call that was prepared last - ask right after the bsmr_sddmm call in question

@@ -22,6 +22,12 @@ def _digest(engine, plan):
     return dict(zip(PARTS, (int(v) for v in out)))
 
 
+def _lists(engine, plan):
+    out = (C.c_uint64 * 5)()
+    assert engine.hip().bsmr_plan_entry_lists_digest(plan, out) == engine.OK
+    return tuple(int(v) for v in out)
+
+
 def _both(engine, rows, cols, ro, ci, alpha, delta, **options):
     csr = engine.CSR.from_arrays(rows, cols, ro, ci)
     pipe = engine.Pipeline(csr, alpha=alpha, delta=delta, device=-1)
@@ -78,6 +84,49 @@ def test_device_packer_equals_host_packer(engine, oracle, name):
         dev = torch.device("cuda:0")
         tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
         tP = torch.full((csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+        engine.sddmm(plans["device"], K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
+        torch.cuda.synchronize()
+        bad, first = oracle.check_data(oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B), tP.cpu().numpy())
+        assert bad == 0, (bad, first)
+    finally:
+        for plan in plans.values():
+            engine.plan_destroy(plan)
+
+
+LIST_CASES = {
+    "nips_full_gemm": (lambda: synth.nips_like(), 0.3, 0.0, {"dense_engine": 5}),
+    "nips_hybrid_tuned": (lambda: synth.nips_like(), 0.3, 0.3, {"dense_engine": 3}),
+    "bernoulli_2048_gemm": (lambda: synth.bernoulli(rows=2048, cols=2048, density=0.1, seed=4), 0.3, 0.0, {"dense_engine": 5}),
+    "mycielskian13_promoted_tuned": (lambda: synth.mycielskian_pattern(k=13), 0.3, 0.3, {"dense_engine": 3}),
+    "ragged_last_panel_sweep": (lambda: synth.random_pattern(1000 + 7, 900, 60000, seed=5, empty_rows=11), 0.3, 0.0, {"dense_engine": 4}),
+    "fem_blocks_tiles": (lambda: synth.fem_node_blocks_like(n=20000, nnz=230000, seed=2), 0.3, 0.3, {"fold_dense_below": 0, "dense_engine": 1}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(LIST_CASES))
+def test_entry_lists_of_the_device_packer_equal_the_hosts(engine, oracle, name):
+    """Plans of the engines that pack their own formats (tiles, shared, sweep, GEMM, tuned) keep the dense entries as
+    per-panel (column, row) lists.  Packed on the device, the plan gets them from the packed blocks (collectEmit); they must
+    be the lists collectDense builds on the host, and the engine must compute from them."""
+    make, alpha, delta, options = LIST_CASES[name]
+    rows, cols, ro, ci = make()
+    csr, plans = _both(engine, rows, cols, ro, ci, alpha, delta, **options)
+    try:
+        host, device = _lists(engine, plans["host"]), _lists(engine, plans["device"])
+        assert host[4] > 0, "the case must keep entry lists"
+        assert device == host
+        assert _digest(engine, plans["device"]) == _digest(engine, plans["host"])
+        t = engine.PlanBuildMs()
+        assert engine.hip().bsmr_plan_build_times(plans["device"], t) == engine.OK
+        print(f"{name}: {host[4]} listed entries, device plan {t.total_ms:.1f} ms (pack {t.pack_ms:.1f})")
+        K = 128
+        A, B = engine.make_data(rows * K, 5489), engine.make_data(cols * K, 5490)
+        dev = torch.device("cuda:0")
+        tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+        tP = torch.full((csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+        if options["dense_engine"] == 3:
+            engine.plan_tune(plans["device"], K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
+            tP.fill_(float("nan"))
         engine.sddmm(plans["device"], K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
         torch.cuda.synchronize()
         bad, first = oracle.check_data(oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B), tP.cpu().numpy())
@@ -228,6 +277,7 @@ def test_plan_from_the_device_arrays_of_the_column_reordering(engine, oracle, na
         assert st == engine.OK
         plans["fetched"] = plan
         assert _digest(engine, plans["resident"]) == _digest(engine, plans["fetched"])
+        assert _lists(engine, plans["resident"]) == _lists(engine, plans["fetched"])
         a, b = engine.PlanStats(), engine.PlanStats()
         assert hip.bsmr_plan_get_stats(plans["fetched"], a) == engine.OK and hip.bsmr_plan_get_stats(plans["resident"], b) == engine.OK
         for field, _ in engine.PlanStats._fields_:
