@@ -27,6 +27,7 @@
 #include "promote_device.hpp"
 #include "plan_pack.hpp"
 #include "plan_promote.hpp"
+#include "plan_evict.hpp"
 #include "sddmm_kernels.hpp"
 #include "tile_format.hpp"
 #include "tile_kernels.hpp"
@@ -137,6 +138,7 @@ struct bsmr_plan {
     bool sparseFree = false;
     uint64_t foldedEntries = 0;    // entries of a small dense part that were moved to the residue
     uint64_t promotedEntries = 0;  // residue entries of the RPHM that the plan computes as extra dense blocks
+    uint64_t evictedEntries = 0;         // dense entries (RPHM) moved to the residue by csrc/plan_evict.hpp
     float buildMs[5] = {0, 0, 0, 0, 0};  // bsmr_plan_build_times: rules, packing, upload, second format, total
     bool packedOnDevice = false;   // fmt[0] was built by csrc/pack_device.hpp
     bool promotedOnDevice = false; // ... from blocks the promotion rule built on the device (csrc/promote_device.hpp)
@@ -2088,6 +2090,7 @@ int bsmr_plan_options_default(bsmr_plan_options* opt) {
     o.gemm_blocks = 0;
     o.gemm_fp32 = -1;
     o.gemm_balance_columns = 1;
+    o.evict_wide_rows = 1;
     *opt = o;
     return BSMR_OK;
 }
@@ -2116,7 +2119,7 @@ int bsmr_plan_options_from_env(bsmr_plan_options* opt) {
         {"BSMR_MASK_TILES", &o.mask_tiles}, {"BSMR_PACK_ON_DEVICE", &o.pack_on_device},
         {"BSMR_SWEEP_PANELS", &o.sweep_panels}, {"BSMR_SWEEP_BLOCKS", &o.sweep_strip_blocks}, {"BSMR_SWEEP_FP32", &o.sweep_fp32},
         {"BSMR_SWEEP_WAVES", &o.sweep_waves}, {"BSMR_SWEEP_PER_CU", &o.sweep_per_cu}, {"BSMR_K_HINT", &o.k_hint}, {"BSMR_PROMOTE_ON_DEVICE", &o.promote_on_device},
-        {"BSMR_GEMM_PANELS", &o.gemm_panels}, {"BSMR_GEMM_BLOCKS", &o.gemm_blocks}, {"BSMR_GEMM_FP32", &o.gemm_fp32}, {"BSMR_GEMM_BALANCE_COLUMNS", &o.gemm_balance_columns},
+        {"BSMR_GEMM_PANELS", &o.gemm_panels}, {"BSMR_GEMM_BLOCKS", &o.gemm_blocks}, {"BSMR_GEMM_FP32", &o.gemm_fp32}, {"BSMR_GEMM_BALANCE_COLUMNS", &o.gemm_balance_columns}, {"BSMR_EVICT_WIDE_ROWS", &o.evict_wide_rows},
     };
     for (const auto& k : knobs) *k.field = envInt(k.name, *k.field);
     return BSMR_OK;
@@ -2394,6 +2397,28 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
             pk = bsmr::PackedPlan();
             st = bsmr::packPlan(d, opt, pk);
             if (st != BSMR_OK) return st;
+            if (pk.tooWide && o.evict_wide_rows != 0 && opt.group == 1 && !res) {
+                // a few (block, row) pairs too wide for the 8-bit windows: they leave the dense part and the plan is built
+                // again from the arrays without them (csrc/plan_evict.hpp); once - the second plan takes what it gets
+                bsmr::EvictedRphm without;
+                if ((st = bsmr::evictWideRows(d, without)) != BSMR_OK) return st;
+                if (without.evicted) {
+                    bsmr_plan_options again = o;
+                    again.evict_wide_rows = 0;
+                    again.fold_dense_below = 0;   // (decided above, on the arrays the caller gave)
+                    again.promote_average = 0;
+                    st = createPlan(out, device, &without.desc, &again, nullptr);
+                    if (st == BSMR_OK) {
+                        (*out)->evictedEntries = without.evicted;
+                        (*out)->promotedEntries += promotedEntries;
+                        (*out)->foldedEntries += foldedEntries;
+                        (*out)->opt.evict_wide_rows = o.evict_wide_rows;
+                        (*out)->opt.fold_dense_below = o.fold_dense_below;
+                        (*out)->opt.promote_average = o.promote_average;
+                    }
+                    return st;
+                }
+            }
         }
         const float packMs = msSince(tPack);
         trace.mark("packing (all of it)");

@@ -150,6 +150,7 @@ struct PackedPlan {
     uint32_t H = 1;
     uint32_t numGroups = 0;
     bool staged = false;
+    bool tooWide = false;                 // the staged encoding was asked for and one (block, row) spans >= kWindowMax entries
     std::vector<uint32_t> panelRows;      // [P*16]   (sparse kernel)
     std::vector<uint32_t> groupRows;      // [G*16H]
     std::vector<uint32_t> rowBase;        // DIRECT: [G*16H] per group row; STAGED: [items*16H] window base
@@ -483,7 +484,7 @@ inline int packPlan(const bsmr_rphm_desc* d, const PackOptions& opt, PackedPlan&
        }
       });
       for (size_t range = 0; range < ranges; ++range) {
-          if (rangeTooWide[range]) out.staged = false;
+          if (rangeTooWide[range]) out.staged = false, out.tooWide = true;
           out.denseItems.insert(out.denseItems.end(), rangeItems[range].begin(), rangeItems[range].end());
           itemLo.insert(itemLo.end(), rangeLo[range].begin(), rangeLo[range].end());
       }

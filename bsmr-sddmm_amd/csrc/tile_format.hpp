@@ -24,6 +24,9 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <memory>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "bsmr_hip.h"
@@ -43,14 +46,37 @@ struct TileItem {
     uint32_t pad;
 };
 
+// A vector whose resize() leaves new elements unwritten: the entry lists are tens to hundreds of MB that the next statement
+// fills; value-initialising them first is one more pass over freshly mapped pages (20 ms for a reddit-like shard).
+template <typename T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <typename U>
+    struct rebind {
+        using other = DefaultInitAllocator<U>;
+    };
+    DefaultInitAllocator() = default;
+    template <typename U>
+    DefaultInitAllocator(const DefaultInitAllocator<U>&) noexcept {}
+    template <typename U>
+    void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) {
+        ::new (static_cast<void*>(p)) U;
+    }
+    template <typename U, typename... Args>
+    void construct(U* p, Args&&... args) {
+        ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+    }
+};
+template <typename T>
+using RawVector = std::vector<T, DefaultInitAllocator<T>>;
+
 // Dense entries of every panel (after the plan's own moves), ordered by (panel, column, row in panel).
 // Kept by the plan on the host: formats for other group sizes are packed from it on demand.
 struct HostDense {
     uint32_t M = 0, N = 0, nnz = 0, numPanels = 0;
     std::vector<uint32_t> panelRows;   // [P*16] original row ids (padding rows repeat row 0 of the list)
     std::vector<uint64_t> offsets;     // [P+1]
-    std::vector<uint32_t> col, idx;
-    std::vector<uint8_t> row;
+    RawVector<uint32_t> col, idx;
+    RawVector<uint8_t> row;
     uint64_t entries() const { return offsets.empty() ? 0 : offsets.back(); }
 };
 

@@ -88,7 +88,7 @@ class PlanOptions(C.Structure):
         "column_order", "dense_stream", "dense_batch", "tile_group", "tile_blocks_per_item", "tile_depth",
         "sparse_entries_per_item", "sparse_lowp", "sparse_lpe", "free_residue", "convert_in_kernel", "convert_sliced",
         "b_only", "b_only_work_m", "overlap_streams", "mask_tiles", "pack_on_device", "sweep_panels", "sweep_strip_blocks",
-        "sweep_fp32", "sweep_waves", "sweep_per_cu", "k_hint", "promote_on_device", "gemm_panels", "gemm_blocks", "gemm_fp32", "gemm_balance_columns")]
+        "sweep_fp32", "sweep_waves", "sweep_per_cu", "k_hint", "promote_on_device", "gemm_panels", "gemm_blocks", "gemm_fp32", "gemm_balance_columns", "evict_wide_rows")]
 
 
 ENGINE_STREAM, ENGINE_TILES, ENGINE_SHARED, ENGINE_TUNED, ENGINE_SWEEP, ENGINE_GEMM = 0, 1, 2, 3, 4, 5

@@ -354,3 +354,23 @@ def write_mtx_columnwise(path, rows, cols, ro, ci, header="%%MatrixMarket matrix
         f.write(header + "\n")
         f.write(f"{rows} {cols} {ci.size}\n")
         np.savetxt(f, np.stack([r[order] + 1, ci[order].astype(np.int64) + 1], 1), fmt="%d")
+
+
+def outlier_row_pattern(groups=40, shared=64, long_row=2000, cols=8000, seed=7):
+    """`groups` clusters of 16 identical rows over `shared` columns spread across [0, cols); the first row of the first
+    cluster also has `long_row` columns of its own between them.  In that row's panel a block's 16 dense columns lie ~2 000
+    ids apart and the long row has ~500 residue entries between two of them: (block, row) pairs that span more than 255
+    entries of P - the outliers csrc/plan_evict.hpp moves to the residue."""
+    rng = np.random.default_rng(seed)
+    per_row = []
+    for g in range(groups):
+        common = np.sort(rng.choice(cols, size=shared, replace=False))
+        for r in range(16):
+            mine = common
+            if g == 0 and r == 0:
+                extra = rng.choice(np.setdiff1d(np.arange(cols), common), size=long_row, replace=False)
+                mine = np.sort(np.concatenate([common, extra]))
+            per_row.append(mine.astype(np.uint32))
+    ro = np.zeros(len(per_row) + 1, dtype=np.uint32)
+    ro[1:] = np.cumsum([len(c) for c in per_row])
+    return len(per_row), cols, ro, np.concatenate(per_row)

@@ -224,6 +224,11 @@ typedef struct bsmr_plan_options {
                                        entries, so that every macro-tile's mask epilogue holds about as many entries (hot
                                        columns - graphs, bag-of-words - otherwise gather in a few macro-tiles the launch waits
                                        for); 0: natural column order                                   [GEMM_BALANCE_COLUMNS] */
+    int32_t  evict_wide_rows;       /* 1 (default): when a (block, row) of the dense part spans 255 or more entries of its row
+                                       (a long row with many residue entries between two dense columns of its panel), the
+                                       entries outside the densest window of 254 become residue, so that the plan keeps
+                                       its 8-bit tiles; only while that moves at most 1 / 16 of the dense entries.  0: such
+                                       a plan takes direct 16-bit offsets for all blocks                  [EVICT_WIDE_ROWS] */
 } bsmr_plan_options;
 int bsmr_plan_options_default(bsmr_plan_options *opt);
 /* defaults, then every BSMR_<NAME> variable that is set */

@@ -402,3 +402,72 @@ extern "C" int plancheck_gemm(const bsmr_rphm_desc* d, uint32_t PM, uint32_t NB,
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+#include "plan_evict.hpp"
+
+// csrc/plan_evict.hpp on the host: packs `d` (default layout), evicts the outlier entries if a (block, row) is too wide for
+// the 8-bit windows, packs again.  Checked here: every stored entry keeps its (panel, row in panel, column) and has exactly
+// one place afterwards - a block cell or the residue -, the panels' column lists and block counts are unchanged, and no
+// (new block, row) of the result spans kWindowMax or more.
+// out[0] too wide before, [1] entries evicted, [2] too wide after, [3] tile bytes after (1 = 8-bit windows),
+// [4] dense entries after, [5] residue entries after, [6] dense entries before.
+extern "C" int plancheck_evict(const bsmr_rphm_desc* d, uint64_t* out) {
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    const uint32_t P = d->num_row_panels;
+    bsmr::PackOptions opt;
+    bsmr::PackedPlan before;
+    if (bsmr::packPlan(d, opt, before) != BSMR_OK) return 1;
+    out[0] = before.tooWide;
+    out[6] = before.numDenseEntries;
+    bsmr::EvictedRphm ev;
+    if (bsmr::evictWideRows(d, ev) != BSMR_OK) return 2;
+    out[1] = ev.evicted;
+    const bsmr_rphm_desc* e = ev.evicted ? &ev.desc : d;
+    // the place of every entry, before and after
+    auto places = [&](const bsmr_rphm_desc* x, std::vector<uint64_t>& where, std::vector<uint8_t>& dense) -> int {
+        where.assign(x->nnz, ~0ull);
+        dense.assign(x->nnz, 0);
+        for (uint32_t q = 0; q < P; ++q) {
+            for (uint64_t b = x->block_offsets[q]; b < x->block_offsets[q + 1]; ++b)
+                for (uint32_t i = 0; i < 256; ++i) {
+                    const uint32_t v = x->block_values[b * 256 + i];
+                    if (v == kNone) continue;
+                    if (v >= x->nnz || where[v] != ~0ull) return 3;
+                    where[v] = ((uint64_t)q << 40) | ((uint64_t)(i / 16) << 32) | x->dense_cols[b * 16 + i % 16];
+                    dense[v] = 1;
+                }
+            for (uint32_t i = x->sparse_value_offsets[q]; i < x->sparse_value_offsets[q + 1]; ++i) {
+                const uint32_t v = x->sparse_values[i];
+                if (v >= x->nnz || where[v] != ~0ull) return 4;
+                where[v] = ((uint64_t)q << 40) | ((uint64_t)x->sparse_relative_rows[i] << 32) | x->sparse_col_indices[i];
+            }
+        }
+        return 0;
+    };
+    std::vector<uint64_t> w0, w1;
+    std::vector<uint8_t> d0, d1;
+    if (int rc = places(d, w0, d0)) return rc;
+    if (int rc = places(e, w1, d1)) return rc + 10;
+    uint64_t moved = 0;
+    for (uint32_t v = 0; v < d->nnz; ++v) {
+        if (w0[v] != w1[v]) return 5;
+        if (d1[v] && !d0[v]) return 6;   // nothing becomes dense
+        moved += d0[v] && !d1[v];
+    }
+    if (moved != ev.evicted) return 7;
+    for (uint32_t q = 0; q <= P; ++q)
+        if (e->block_offsets[q] != d->block_offsets[q]) return 8;
+    for (uint64_t i = 0; i < (uint64_t)d->block_offsets[P] * 16; ++i)
+        if (e->dense_cols[i] != d->dense_cols[i]) return 9;
+    bsmr::PackedPlan after;
+    if (bsmr::packPlan(e, opt, after) != BSMR_OK) return 20;
+    out[2] = after.tooWide;
+    out[3] = after.staged ? 1 : (after.tiles16.empty() ? 4 : 2);
+    out[4] = after.numDenseEntries;
+    out[5] = after.numSparseEntries;
+    if (after.numDenseEntries + after.numSparseEntries != d->nnz) return 21;
+    if (ev.evicted && after.numDenseEntries + ev.evicted != before.numDenseEntries) return 22;
+    if (ev.evicted && after.numBlocks != before.numBlocks) return 23;
+    return 0;
+}

@@ -155,6 +155,50 @@ def test_inputs_left_to_the_host_packer(engine):
             engine.plan_destroy(plan)
 
 
+def test_outlier_rows_leave_the_dense_part(engine, oracle):
+    """csrc/plan_evict.hpp: one long row used to flip the whole plan to direct 16-bit offsets; now the few entries of
+    that row outside the 8-bit windows become residue and the plan keeps its 8-bit tiles.  Every entry is still computed
+    exactly once, by one of the two kernels."""
+    rows, cols, ro, ci = synth.outlier_row_pattern()
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    arrays = engine.Pipeline(csr, alpha=0.3, delta=0.3, device=-1).arrays()
+    plans, stats = {}, {}
+    try:
+        for name, flag in (("kept", 0), ("evicted", 1)):
+            st, plan = engine.plan_from_arrays(rows, cols, csr.nnz, arrays, device=0,
+                                               options=engine.plan_options(evict_wide_rows=flag, promote_average=0, fold_dense_below=0))
+            assert st == engine.OK, name
+            plans[name] = plan
+            stats[name] = engine.PlanStats()
+            assert engine.hip().bsmr_plan_get_stats(plan, stats[name]) == engine.OK
+        empty = 0xcbf29ce484222325           # FNV-1a of nothing: the array is not part of the format
+        kept, evicted = _digest(engine, plans["kept"]), _digest(engine, plans["evicted"])
+        assert kept["winLen"] == empty, "the case must hold a (block, row) wider than a window"
+        assert evicted["winLen"] != empty, "8-bit windows after the eviction"
+        moved = stats["evicted"].num_sparse_entries - stats["kept"].num_sparse_entries
+        assert 0 < moved * 16 <= stats["kept"].num_dense_entries
+        assert stats["evicted"].num_dense_entries + stats["evicted"].num_sparse_entries == csr.nnz
+        assert stats["evicted"].num_dense_blocks == stats["kept"].num_dense_blocks      # the column lists stay
+        print(f"outlier row: {moved} of {stats['kept'].num_dense_entries} dense entries moved to the residue")
+        K = 64
+        A, B = engine.make_data(rows * K, 5489), engine.make_data(cols * K, 5490)
+        dev = torch.device("cuda:0")
+        tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+        want = oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B)
+        for name, plan in plans.items():
+            flags = np.zeros(csr.nnz, dtype=np.uint8)
+            assert engine.hip().bsmr_plan_dense_flags(plan, flags.ctypes.data_as(C.c_void_p)) == engine.OK
+            assert int(flags.sum()) == getattr(stats[name], "num_dense_entries")
+            tP = torch.full((csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+            engine.sddmm(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
+            torch.cuda.synchronize()
+            bad, first = oracle.check_data(want, tP.cpu().numpy())
+            assert bad == 0, (name, bad, first)
+    finally:
+        for plan in plans.values():
+            engine.plan_destroy(plan)
+
+
 def test_build_times_say_where_the_format_was_packed(engine):
     rows, cols, ro, ci = synth.nips_like()
     csr, plans = _both(engine, rows, cols, ro, ci, 0.3, 0.0)

@@ -322,3 +322,54 @@ def test_gemm_format_rejects_shapes_it_cannot_hold(gemmcheck):
     rows, cols, ro, ci = synth.random_pattern(40, 60, 500, seed=2)
     assert gemmcheck(rows, cols, ro, ci, 0.3, 0.0, 12, 16)[0] == 201     # panels per macro-tile: 8 or 16
     assert gemmcheck(rows, cols, ro, ci, 0.3, 0.0, 16, 24)[0] == 201     # blocks per macro-tile: 8, 12, 16, 20
+
+
+@pytest.fixture(scope="module")
+def evictcheck(engine):
+    lib = C.CDLL(str(REPO / "tests" / "native" / "libplancheck.so"))
+    lib.plancheck_evict.restype = C.c_int
+    lib.plancheck_evict.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+
+    def run(rows, cols, ro, ci, alpha, delta):
+        csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+        arrays = engine.Pipeline(csr, alpha=alpha, delta=delta, device=-1).arrays()
+        keep = {k: np.ascontiguousarray(arrays[k], dtype=np.uint32) for k in
+                ("reorderedRows", "denseCols", "blockOffsets", "blockValues", "sparseValueOffsets",
+                 "sparseValues", "sparseRelativeRows", "sparseColIndices")}
+        d = engine.RphmDesc()
+        d.M, d.N, d.nnz = rows, cols, csr.nnz
+        d.num_nonzero_rows = keep["reorderedRows"].size
+        d.num_row_panels = keep["blockOffsets"].size - 1
+        cast = lambda a: a.ctypes.data_as(engine.u32p)
+        d.reordered_rows, d.dense_cols = cast(keep["reorderedRows"]), cast(keep["denseCols"])
+        d.block_offsets, d.block_values = cast(keep["blockOffsets"]), cast(keep["blockValues"])
+        d.sparse_value_offsets, d.sparse_values = cast(keep["sparseValueOffsets"]), cast(keep["sparseValues"])
+        d.sparse_relative_rows, d.sparse_col_indices = cast(keep["sparseRelativeRows"]), cast(keep["sparseColIndices"])
+        out = (C.c_uint64 * 7)()
+        rc = lib.plancheck_evict(C.byref(d), out)
+        return rc, dict(zip(("wide_before", "evicted", "wide_after", "tile_bytes", "dense", "residue", "dense_before"), (int(v) for v in out)))
+    return run
+
+
+def test_outlier_entries_are_evicted_and_the_windows_fit(evictcheck):
+    """One long row with hundreds of residue entries between the dense columns of its panel (csrc/plan_evict.hpp): a few of
+    its entries leave the dense part, every entry keeps its place in the matrix, and the plan packs with 8-bit windows."""
+    rc, r = evictcheck(*synth.outlier_row_pattern(), 0.3, 0.3)
+    assert rc == 0, (rc, r)
+    assert r["wide_before"] == 1 and r["wide_after"] == 0 and r["tile_bytes"] == 1, r
+    assert 0 < r["evicted"] * 16 <= r["dense_before"], r
+    assert r["dense"] == r["dense_before"] - r["evicted"], r
+
+
+def test_eviction_leaves_other_patterns_alone(evictcheck):
+    """Nothing is too wide in a pattern with sorted rows and an all-dense split; with unsorted CSR rows nearly every block
+    is, which is not a matter of outliers: the arrays stay as they are (the plan then takes direct offsets, as before)."""
+    rc, r = evictcheck(*synth.nips_like(rows=320, cols=1500, nnz=40000, seed=1), 0.3, 0.0)
+    assert rc == 0 and r["wide_before"] == 0 and r["evicted"] == 0, (rc, r)
+    rng = np.random.default_rng(3)
+    rows, cols = 64, 6000
+    per_row = [rng.permutation(cols)[:3000] for _ in range(rows)]
+    ro = np.zeros(rows + 1, dtype=np.uint32)
+    ro[1:] = np.cumsum([len(c) for c in per_row])
+    rc, r = evictcheck(rows, cols, ro, np.concatenate(per_row).astype(np.uint32), 0.3, 0.0)
+    assert rc == 0 and r["wide_before"] == 1 and r["evicted"] == 0 and r["wide_after"] == 1, (rc, r)

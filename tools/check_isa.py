@@ -212,7 +212,7 @@ def check(name, body, strict=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("asm")
-    ap.add_argument("--kernels", default=r"dense(Stream|Tiles|Shared|Groups|Sweep)|sparseEntries|isaTrap")
+    ap.add_argument("--kernels", default=r"dense(Stream|Tiles|Shared|Groups|Sweep|Gemm)|sparseEntries|isaTrap")
     ap.add_argument("--expect-violation", action="store_true")
     ap.add_argument("--strict", action="store_true")
     args = ap.parse_args()
