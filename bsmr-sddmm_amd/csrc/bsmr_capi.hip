@@ -3579,22 +3579,46 @@ int clusterRows(int device, uint32_t rows, uint32_t cols, const uint32_t* row_of
             bool many = false;
             uint64_t lastWork = 0, lastPasses = 0;
             int batch = 4;
+            // Which of the two scheduling rules of a pass (cluster_kernels.hpp, step 5) a batch runs under: clusters running
+            // AHEAD of the older ones' decisions whenever the kernel's own evidence allows it (few passes, some of what they
+            // judge is for nothing; rule 0, the default) or only BEHIND them (round 2's rule; rule 1).  BSMR_CLUSTER_RULE=2
+            // chooses by measurement: rows that got their cluster per millisecond of a batch, two trial batches of 64 passes -
+            // one per rule, in alternating order - then the faster rule for the next 2 048 passes (the other one has to be
+            // 10 % faster to take over).  Measured on MI355X (profiles/r04_cluster_device_lab.md): "behind" wins on one of
+            // eight patterns, by 6 % (wathen100), and loses up to 3.2x (reddit-like shard); the trials themselves cost more
+            // than that - a trial of "behind" harvests what the passes ahead of it judged and looks better than it is - so
+            // the measured choice stays a lab switch.
+            const uint32_t capOf[2] = {bsmr::kClusterMaxActive, bsmr::kClusterSpeculateFrom - 1u};
+            const int ruleKnob = envInt("BSMR_CLUSTER_RULE", 0);
+            const int pinned = ruleKnob == 2 ? -1 : (ruleKnob == 1 ? 1 : 0);
+            int rule = pinned == 1 ? 1 : 0;
+            enum { kWarmUp, kTrialFirst, kTrialSecond, kHold } phase = pinned >= 0 ? kHold : kWarmUp;
+            int holdLeft = 0, trials = 0;
+            double trialRate[2] = {0, 0};
+            uint32_t lastAssigned = 0, switches = 0;
             while (!state.done) {
                 if (enqueued > passLimit) {
                     g_lastHipError = "bsmr_cluster_rows: pass limit reached";
                     return BSMR_ERR_HIP;
                 }
-                for (int i = 0; i < batch; ++i) {
+                if (pinned < 0) {
+                    if (phase == kWarmUp && batch >= 64) phase = kTrialFirst;
+                    if (phase == kTrialFirst) rule = (trials & 1) ? 1 - rule : rule;          // (alternating order: the current rule first, then second)
+                    else if (phase == kTrialSecond) rule = 1 - rule;
+                }
+                const int launchNow = pinned < 0 && (phase == kTrialFirst || phase == kTrialSecond) ? 64 : batch;
+                const auto tBatch = std::chrono::steady_clock::now();
+                for (int i = 0; i < launchNow; ++i) {
                     if (many)
                         hipLaunchKernelGGL(bsmr::clusterPass<true>, dim3(grid), dim3(T), 0, s, dTable, dSquares, dTotals, dPosInfo,
                                            dEncWords, dOrder, rows, (uint32_t)numBins, alpha, maxChunk, active, live, longRow,
-                                           dReps, dCluster, dState, (uint32_t)(enqueued + (uint64_t)i));
+                                           dReps, dCluster, dState, (uint32_t)(enqueued + (uint64_t)i), capOf[rule]);
                     else
                         hipLaunchKernelGGL(bsmr::clusterPass<false>, dim3(grid), dim3(T), 0, s, dTable, dSquares, dTotals, dPosInfo,
                                            dEncWords, dOrder, rows, (uint32_t)numBins, alpha, maxChunk, active, live, longRow,
-                                           dReps, dCluster, dState, (uint32_t)(enqueued + (uint64_t)i));
+                                           dReps, dCluster, dState, (uint32_t)(enqueued + (uint64_t)i), capOf[rule]);
                 }
-                enqueued += (uint64_t)batch;
+                enqueued += (uint64_t)launchNow;
                 batch = std::min(256, batch * 4);
                 BSMR_HIP(hipGetLastError());
                 // the state the last launch left: the copy launch number `enqueued` would read - or, when the passes ended
@@ -3602,13 +3626,38 @@ int clusterRows(int device, uint32_t rows, uint32_t cols, const uint32_t* row_of
                 bsmr::ClusterState both[2];
                 BSMR_HIP(hipMemcpyAsync(both, dState, sizeof(both), hipMemcpyDeviceToHost, s));
                 BSMR_HIP(hipStreamSynchronize(s));
+                const double batchMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tBatch).count();
                 state = both[0].done || both[1].done ? (both[0].passes >= both[1].passes ? both[0] : both[1]) : both[enqueued & 1u];
                 const uint64_t work = (uint64_t)state.judged + state.exact, passes = state.passes;
                 if (passes > lastPasses) many = (work - lastWork) > (uint64_t)grid * (passes - lastPasses);
                 if (many && !dEncOffsets && (st = uploadSparseRows()) != BSMR_OK) return st;
                 lastWork = work;
                 lastPasses = passes;
+                const double rate = (double)(state.assigned - lastAssigned) / std::max(batchMs, 1e-3);
+                lastAssigned = state.assigned;
+                if (pinned < 0) {
+                    if (phase == kTrialFirst) {
+                        trialRate[rule] = rate;
+                        phase = kTrialSecond;
+                    } else if (phase == kTrialSecond) {
+                        trialRate[rule] = rate;
+                        // `rule` is the one tried second; the one in force before the trial is the first of an even trial,
+                        // the second of an odd one
+                        const int inForce = (trials & 1) ? rule : 1 - rule, other = 1 - inForce;
+                        const int next = trialRate[other] > 1.1 * trialRate[inForce] ? other : inForce;
+                        switches += next != inForce;
+                        rule = next;
+                        ++trials;
+                        phase = kHold;
+                        holdLeft = 8;
+                    } else if (phase == kHold && --holdLeft <= 0) {
+                        phase = kTrialFirst;
+                    }
+                }
             }
+            if (envInt("BSMR_CLUSTER_TRACE", 0))
+                fprintf(stderr, "bsmr_cluster_rows: %u passes, %d rule trials, %u switches, last rule %s\n", state.passes, trials, switches,
+                        rule ? "behind" : "ahead");
             BSMR_HIP(hipMemcpyAsync(cluster.data(), dCluster, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
             BSMR_HIP(hipStreamSynchronize(s));
             // ids count the seeds, dropped tentative ones included: dense numbering in the same order

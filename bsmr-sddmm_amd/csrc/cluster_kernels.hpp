@@ -103,6 +103,8 @@ struct ClusterState {
     uint32_t startChunk; // first chunk of a new cluster: running mean of the chunks finished clusters ended with
     uint32_t totalItems; // what the next pass judges, all clusters together (a workgroup without an item leaves before it loads the slots:
                          // 512 workgroups reading the same 2 KB were a hot spot in one L2 channel)
+    uint32_t assigned;   // rows that have their cluster for good (confirmed seeds + accepted rows): what the host measures the two
+                         // scheduling rules by (bsmr_cluster_rows: rows per millisecond of a batch of passes)
     ClusterSlot slot[kClusterMaxActive];
 #ifdef BSMR_LAB_STAMPS
     unsigned long long stamps[16];   // lab build: cycles of the closing workgroup per phase, summed over the passes
@@ -237,7 +239,7 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
                             const uint32_t* __restrict__ encWords,
                             const uint32_t* __restrict__ order, uint32_t rows, uint32_t numBins, float alpha,
                             uint32_t maxChunk, uint32_t maxActive, uint32_t liveWarps, uint32_t longRow, uint32_t* __restrict__ reps,
-                            uint32_t* __restrict__ cluster, ClusterState* __restrict__ states, uint32_t ordinal) {
+                            uint32_t* __restrict__ cluster, ClusterState* __restrict__ states, uint32_t ordinal, uint32_t tentativeCap) {
     // Two copies of the state, used in turn: launch number `ordinal` READS states[ordinal & 1] - nothing but the atomics of
     // its own participants (arrived, judged, exact, a slot's firstHit) touches that copy while the launch runs - and its
     // closing workgroup WRITES the next pass's state into the other copy.  A workgroup that has no item in this pass and is
@@ -267,7 +269,7 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
     // (what the closing workgroup needs of the state is read here, together with the rest: it changes at the end of a pass only)
     const uint32_t tentativeIn = state->tentative, scanPosIn = state->scanPos, nextIdIn = state->nextId;
     const uint32_t freeRepsIn = state->freeReps, startChunkIn = state->startChunk;
-    const uint32_t passesIn = state->passes, aheadIn = state->ahead, droppedIn = state->dropped;
+    const uint32_t passesIn = state->passes, aheadIn = state->ahead, droppedIn = state->dropped, assignedIn = state->assigned;
     const bool speculate = tentativeIn >= kClusterSpeculateFrom;
     {
         const uint32_t itemsIn = state->totalItems;
@@ -800,6 +802,8 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
     // that kind - the reddit-like shard spent 4 900 of 8 783 passes there.
     if (dropped) tentative >>= 1;
     else if ((confirmedNow || certain || hitsNow * 4u < judging) && tentative < maxActive) ++tentative;
+    // (the host's choice between the two rules of step 5: a cap below kClusterSpeculateFrom keeps the passes to round 2's rule)
+    if (tentative > tentativeCap) tentative = tentativeCap;
     if (threadIdx.x < numNew) {
         const uint32_t u = sNew[threadIdx.x], row = order[u];
         ClusterSlot c;
@@ -865,6 +869,7 @@ clusterPass(const ClusterCount* __restrict__ table, const uint32_t* __restrict__
         next->ahead = aheadIn + (speculate ? 1u : 0u);
         next->dropped = droppedIn + dropped;
         next->tentative = tentative;
+        next->assigned = assignedIn + confirmedNow + hitsNow + certain;
         next->startChunk = startChunk;
         next->totalItems = shared[3];
 #ifdef BSMR_LAB_STAMPS

@@ -124,3 +124,23 @@ def test_a_grid_larger_than_the_pass_keeps_the_host_order(engine, monkeypatch):
         st, perm, clusters, stats = engine.cluster_rows_device(rows, cols, ro, ci, 16, alpha)
         pipe = engine.Pipeline(engine.CSR.from_arrays(rows, cols, ro, ci), alpha=alpha, delta=0.3, block_size=16, device=-1)
         assert st == engine.OK and np.array_equal(pipe.array("reorderedRows"), perm) and pipe.num_clusters == clusters
+
+
+@pytest.mark.parametrize("rule", [1, 2])
+def test_either_scheduling_rule_gives_the_host_order(engine, monkeypatch, rule):
+    """BSMR_CLUSTER_RULE: 1 = clusters only judge what every older one has decided (round 2's rule, the kernel's cap on
+    clusters that may run unconfirmed), 2 = the host switches between the two rules by the measured rows per millisecond,
+    batch by batch.  What a pass may judge early changes, what the clusters are does not: row order and cluster count stay
+    the host implementation's."""
+    monkeypatch.setenv("BSMR_CLUSTER_RULE", str(rule))
+    cases = [(synth.reddit_shard_like(rows=6000, seed=5), None), (synth.wathen_pattern(nx=30, ny=30), 16), (synth.nips_like(), None)]
+    for (rows, cols, ro, ci), block in cases:
+        csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+        bw = block or csr.calculate_block_size(200 << 30)
+        for alpha in (0.3, 0.6):
+            st, perm, clusters, stats = engine.cluster_rows_device(rows, cols, ro, ci, bw, alpha)
+            assert st == engine.OK
+            pipe = engine.Pipeline(csr, alpha=alpha, delta=0.3, block_size=bw, device=-1)
+            assert np.array_equal(pipe.array("reorderedRows"), perm) and pipe.num_clusters == clusters, (rule, rows, alpha, stats)
+            if rule == 1:
+                assert stats["passes_ahead"] <= 1, stats

@@ -32,7 +32,7 @@ def main():
         bw = csr.calculate_block_size(200 << 30)
         for alpha in alphas:
             best, stats = 1e30, None
-            for _ in range(2):
+            for _ in range(3):
                 t0 = time.perf_counter()
                 st, perm, clusters, s = eng.cluster_rows_device(rows, cols, ro, ci, bw, alpha)
                 wall = (time.perf_counter() - t0) * 1e3
