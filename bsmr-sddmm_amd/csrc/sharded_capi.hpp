@@ -225,11 +225,52 @@ int bsmr_sharded_create(bsmr_sharded** out, const int* devices, uint32_t num_dev
         s->gathered[b].assign(num_devices, nullptr);
     }
     int st = BSMR_OK;
+    for (uint32_t i = 0; i < num_devices; ++i) s->entryBegin[i + 1] = s->entryBegin[i] + shard_descs[i]->nnz;
+    {
+        // the shards' plans: one host thread per distinct device (BSMR_SHARD_BUILD_THREADS=n: n threads whatever the devices
+        // are), every thread its shards in turn.  (A row range without rows - more shards than non-empty row panels - has no
+        // plan and takes no part in a step.)
+        std::vector<std::vector<uint32_t>> lanes;
+        const int forced = std::max(0, envInt("BSMR_SHARD_BUILD_THREADS", 0));
+        if (forced > 0) {
+            lanes.assign(std::min<size_t>((size_t)forced, num_devices), {});
+            for (uint32_t i = 0; i < num_devices; ++i) lanes[i % lanes.size()].push_back(i);
+        } else {
+            lanes.assign(s->uniqueDevices.size(), {});
+            for (uint32_t i = 0; i < num_devices; ++i) lanes[(size_t)s->rankOf[i]].push_back(i);
+        }
+        std::vector<int> laneStatus(lanes.size(), BSMR_OK);
+        std::vector<std::string> laneError(lanes.size());
+        auto buildLane = [&](size_t t) {
+            for (const uint32_t i : lanes[t]) {
+                if (shard_descs[i]->M == 0 || shard_descs[i]->nnz == 0) continue;
+                int one = BSMR_ERR_INVALID_ARG;
+                try {
+                    one = bsmr_plan_create_ex(&s->plans[i], devices[i], shard_descs[i], options);
+                } catch (...) {
+                    one = BSMR_ERR_OOM;
+                }
+                if (one != BSMR_OK) {
+                    laneStatus[t] = one;
+                    laneError[t] = g_lastHipError;   // (thread-local: carried to the calling thread below)
+                    return;
+                }
+            }
+        };
+        if (lanes.size() <= 1) {
+            if (!lanes.empty()) buildLane(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t < lanes.size(); ++t) pool.emplace_back(buildLane, t);
+            for (std::thread& th : pool) th.join();
+        }
+        for (size_t t = 0; t < lanes.size() && st == BSMR_OK; ++t)
+            if (laneStatus[t] != BSMR_OK) {
+                st = laneStatus[t];
+                g_lastHipError = laneError[t];
+            }
+    }
     for (uint32_t i = 0; i < num_devices && st == BSMR_OK; ++i) {
-        s->entryBegin[i + 1] = s->entryBegin[i] + shard_descs[i]->nnz;
-        // (a row range without rows - more shards than non-empty row panels - has no plan and takes no part in a step)
-        if (shard_descs[i]->M != 0 && shard_descs[i]->nnz != 0) st = bsmr_plan_create_ex(&s->plans[i], devices[i], shard_descs[i], options);
-        if (st != BSMR_OK) break;
         if (hipSetDevice(devices[i]) != hipSuccess) {
             (void)hipGetLastError();
             st = BSMR_ERR_NO_DEVICE;

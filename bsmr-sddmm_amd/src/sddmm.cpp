@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <fstream>
 #include <memory>
+#include <exception>
+#include <thread>
 #include <vector>
 
 #include "bsmr_hip.h"
@@ -152,6 +154,13 @@ void sddmm_multi_gpu(const Options& options, const Matrix<float>& matrixA, const
         std::vector<UIN> ro(static_cast<size_t>(r1 - r0) + 1), ci(matrixP.colIndices().begin() + e0, matrixP.colIndices().begin() + e1);
         for (UIN r = r0; r <= r1; ++r) ro[r - r0] = matrixP.rowOffsets()[r] - e0;
         slices.emplace_back(r1 - r0, matrixP.col(), e1 - e0, ro, ci);
+    }
+    // The shards' pipelines are independent (the row ranges are disjoint, reference src/BSMR.cpp:678-711): one host thread per
+    // DISTINCT device builds the shards of that device one after another - eight devices cluster their slices side by side
+    // instead of 8 x ~0.4 s in a row.  BSMR_SHARD_BUILD_THREADS=n: n threads whatever the devices are (several shards of one
+    // device then build side by side too; their device work shares that device's default stream).
+    std::vector<float> shardTime(world, 0.0f);
+    auto buildShard = [&](int i) {
         struct DeviceScope {   // clustering of this slice on the slice's device
             int before = pipelineDevice();
             explicit DeviceScope(int d) { setPipelineDevice(d); }
@@ -159,7 +168,7 @@ void sddmm_multi_gpu(const Options& options, const Matrix<float>& matrixA, const
         } scope(devices[i]);
         bsmrs[i] = BSMR(options.similarityThresholdAlpha(), options.blockDensityThresholdDelta(), slices[i], 1);
         rphms[i].reset(new RPHM(slices[i], bsmrs[i], -1));   // host arrays; the device side is bsmr_sharded_create
-        reordering = std::max(reordering, bsmrs[i].reorderingTime() + rphms[i]->time());
+        shardTime[i] = bsmrs[i].reorderingTime() + rphms[i]->time();
         bsmr_rphm_desc& d = descs[i];
         d = bsmr_rphm_desc{};
         d.M = slices[i].row();
@@ -176,7 +185,45 @@ void sddmm_multi_gpu(const Options& options, const Matrix<float>& matrixA, const
         d.sparse_relative_rows = rphms[i]->sparseRelativeRows().data();
         d.sparse_col_indices = rphms[i]->sparseColIndices().data();
         descPtrs[i] = &d;
+    };
+    {
+        std::vector<std::vector<int>> lanes;   // shard numbers per builder thread
+        int forced = 0;
+        if (const char* env = std::getenv("BSMR_SHARD_BUILD_THREADS")) forced = std::max(0, std::atoi(env));
+        if (forced > 0) {
+            lanes.assign(static_cast<size_t>(std::min(forced, world)), {});
+            for (int i = 0; i < world; ++i) lanes[static_cast<size_t>(i) % lanes.size()].push_back(i);
+        } else {
+            std::vector<int> seen;
+            for (int i = 0; i < world; ++i) {
+                size_t u = 0;
+                while (u < seen.size() && seen[u] != devices[i]) ++u;
+                if (u == seen.size()) {
+                    seen.push_back(devices[i]);
+                    lanes.emplace_back();
+                }
+                lanes[u].push_back(i);
+            }
+        }
+        if (lanes.size() <= 1) {
+            for (int i = 0; i < world; ++i) buildShard(i);
+        } else {
+            std::vector<std::thread> pool;
+            std::vector<std::exception_ptr> failed(lanes.size());
+            for (size_t t = 0; t < lanes.size(); ++t)
+                pool.emplace_back([&, t]() {
+                    try {
+                        for (const int i : lanes[t]) buildShard(i);
+                    } catch (...) {
+                        failed[t] = std::current_exception();
+                    }
+                });
+            for (std::thread& th : pool) th.join();
+            for (const std::exception_ptr& f : failed)
+                if (f) std::rethrow_exception(f);
+        }
     }
+    for (int i = 0; i < world; ++i) reordering = std::max(reordering, shardTime[i]);
     logger.reorderingTime_ = reordering;
     bsmr_plan_options opts;
     bsmr_plan_options_from_env(&opts);

@@ -1048,7 +1048,25 @@ def test_several_shards_on_one_device(engine, oracle, shards):
     assert np.array_equal(got, (hot[r, 0] + colid[ci, 1]).astype(np.float32))
 
 
-def test_reddit_full_graph_in_eight_shards_on_one_device(engine, oracle, capsys):
+def test_shards_built_on_several_host_threads(engine, oracle, monkeypatch):
+    """sddmm_multi_gpu / bsmr_sharded_create build the shards of different devices on one host thread per device.  On a
+    one-GPU box BSMR_SHARD_BUILD_THREADS puts the shards of the one device on several threads: pipelines (device clustering
+    included) and plans built side by side give the result of the builds in a row, bit for bit in the exact fp32 mode."""
+    rows, cols, ro, ci = synth.reddit_like_rows(0, 12000, n=12000, avg_degree=80, communities=8)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    K = 64
+    A, B = engine.make_data(rows * K, 5489), engine.make_data(cols * K, 5490)
+    in_a_row, _ = engine.sddmm_operator_sharded(csr, K, A, B, [0] * 6, alpha=0.3, delta=0.0, mode=engine.COMPUTE_F32)
+    monkeypatch.setenv("BSMR_SHARD_BUILD_THREADS", "3")
+    for _ in range(2):
+        side_by_side, _ = engine.sddmm_operator_sharded(csr, K, A, B, [0] * 6, alpha=0.3, delta=0.0, mode=engine.COMPUTE_F32)
+        assert np.array_equal(in_a_row.view(np.uint32), side_by_side.view(np.uint32))
+    got, _ = engine.sddmm_operator_sharded(csr, K, A, B, [0] * 6, alpha=0.3, delta=0.3)
+    bad, first = oracle.check_data(oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B), got)
+    assert bad == 0, (bad, first)
+
+
+def test_reddit_full_graph_in_eight_shards_on_one_device(engine, oracle, capsys, monkeypatch):
     """BASELINE configs[3] ITSELF through the N > 1 path: the reddit-like graph at full size (232 965^2, 114 618 780 stored
     entries - reddit's count), K = 256, fp16, cut by cost into EIGHT row ranges, every range its own pipeline + plan
     (bsmr_sharded_* behind sddmm_multi_gpu), all eight on the one visible device: partition, per-shard plans, rows of A,
@@ -1093,13 +1111,18 @@ def test_reddit_full_graph_in_eight_shards_on_one_device(engine, oracle, capsys)
     colid = np.zeros((cols, K), dtype=np.float32)
     colid[:, 0] = 1.0
     colid[:, 1] = np.arange(cols) % 127
+    # (this second build of the eight shards on four host threads: on an 8-GPU node every device has its own)
+    monkeypatch.setenv("BSMR_SHARD_BUILD_THREADS", "4")
+    t0 = time.perf_counter()
     placed, _ = engine.sddmm_operator_sharded(csr, K, hot.ravel(), colid.ravel(), [0] * shards, alpha=0.3, delta=0.3)
+    t_threads = time.perf_counter() - t0
     r = np.repeat(np.arange(rows, dtype=np.int64), d)
     assert np.array_equal(placed, (hot[r, 0] + colid[ci, 1]).astype(np.float32))
     with capsys.disabled():
         print(f"\n[configs[3] in {shards} shards on one device] graph {t_graph:.1f} s, pipelines + plans + 3 steps {t_sharded:.1f} s, "
               f"{ms:.3f} ms per pipelined step (8 SDDMMs + gather on ONE GPU; one step taken apart: SDDMMs {times['compute_ms']:.3f} ms, gather {times['gather_ms']:.3f} ms), cost imbalance {imbalance:.4f}, oracle {t_oracle:.1f} s, "
-              f"max relative error {rel:.2e}, 0 of {ci.size} entries fail checkData, placement exact")
+              f"max relative error {rel:.2e}, 0 of {ci.size} entries fail checkData, placement exact; "
+              f"pipelines + plans + 1 step with 4 builder threads {t_threads:.1f} s")
 
 
 @pytest.mark.shipping_rules
