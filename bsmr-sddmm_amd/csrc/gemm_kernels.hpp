@@ -286,15 +286,6 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
     const uint32_t* rowTable = reinterpret_cast<const uint32_t*>(lds + rowTableAt) + wm * (TM / 2u);
 #pragma unroll
     for (uint32_t q = 0; q < Q; ++q) {
-#if defined(BSMR_GEMM_DUMP_B128)
-        if (!GEMM_LAB_SKIP(3)) {
-#pragma unroll
-            for (uint32_t tp = 0; tp < kGemmPassTiles; ++tp) {
-                const uint32_t tIdx = q * kGemmPassTiles + tp;
-                if (tIdx < m * n) *reinterpret_cast<f32x4*>(slab + (tp * 64u + lane) * 4u) = acc[tIdx / n][tIdx % n];
-            }
-        }
-#else
         if (!GEMM_LAB_SKIP(3)) {
             if (slabAddr < 0x10000u) {
 #pragma unroll
@@ -310,7 +301,6 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
                 }
             }
         }
-#endif
         const uint32_t first = myList[q], last = myList[q + 1u];
         uint32_t w[kGemmWordChunk];
 #pragma unroll
@@ -509,15 +499,6 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
     const uint32_t* rowTable = reinterpret_cast<const uint32_t*>(lds + rowTableAt) + wm * (TM / 2u);
 #pragma unroll
     for (uint32_t q = 0; q < Q; ++q) {
-#if defined(BSMR_GEMM_DUMP_B128)
-        if (!GEMM_LAB_SKIP(3)) {
-#pragma unroll
-            for (uint32_t tp = 0; tp < kGemmPassTiles; ++tp) {
-                const uint32_t tIdx = q * kGemmPassTiles + tp;
-                if (tIdx < m * n) *reinterpret_cast<f32x4*>(slab + (tp * 64u + lane) * 4u) = acc[tIdx / n][tIdx % n];
-            }
-        }
-#else
         if (!GEMM_LAB_SKIP(3)) {
             if (slabAddr < 0x10000u) {
 #pragma unroll
@@ -533,7 +514,6 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
                 }
             }
         }
-#endif
         const uint32_t first = myList[q], last = myList[q + 1u];
         uint32_t w[kGemmWordChunk];
 #pragma unroll
