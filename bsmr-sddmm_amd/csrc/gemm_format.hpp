@@ -60,11 +60,7 @@ namespace bsmr {
 constexpr uint32_t kGemmWavesM = 2, kGemmWavesN = 4, kGemmWaves = kGemmWavesM * kGemmWavesN;
 // where the epilogue's dump leaves accumulator cell (r, c) of the pass's tile tp, in floats from the wave's slab: register
 // r & 3 of lane 16 (r >> 2) + c; one register of all 64 lanes = 256 contiguous bytes (one ds_write_addtid_b32)
-#if defined(BSMR_GEMM_DUMP_B128)   // lab: the dump as one ds_write_b128 per tile and lane
-__host__ __device__ constexpr uint32_t gemmSlabSlot(uint32_t tp, uint32_t r, uint32_t c) { return (tp * 64u + (r >> 2) * 16u + c) * 4u + (r & 3u); }
-#else
 __host__ __device__ constexpr uint32_t gemmSlabSlot(uint32_t tp, uint32_t r, uint32_t c) { return tp * 256u + (r & 3u) * 64u + (r >> 2) * 16u + c; }
-#endif
 constexpr uint32_t kGemmPassTiles = 16;        // 16 x 16 tiles of a wave per slab pass (16 KiB of fp32 per wave)
 constexpr uint32_t kGemmNoEntry = 0xFFFFFFFFu; // padding word (offset 8191 is never a real offset)
 constexpr uint32_t kGemmMaxOffset = 8191u;
