@@ -139,6 +139,10 @@ struct bsmr_plan {
     uint64_t foldedEntries = 0;    // entries of a small dense part that were moved to the residue
     uint64_t promotedEntries = 0;  // residue entries of the RPHM that the plan computes as extra dense blocks
     uint64_t evictedEntries = 0;         // dense entries (RPHM) moved to the residue by csrc/plan_evict.hpp
+    // a tunable plan's second, grouped format is packed when the tuner first wants to measure it (ensureGrouped): the host
+    // packer needs 65 ms for it on the 4096^2 plan whose calls the GEMM engine then serves anyway
+    bool groupedDeferred = false;
+    bsmr::PackOptions groupedOpt;
     float buildMs[5] = {0, 0, 0, 0, 0};  // bsmr_plan_build_times: rules, packing, upload, second format, total
     bool packedOnDevice = false;   // fmt[0] was built by csrc/pack_device.hpp
     bool promotedOnDevice = false; // ... from blocks the promotion rule built on the device (csrc/promote_device.hpp)
@@ -915,6 +919,54 @@ int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, con
     f = out;
     indexBytes += bytes;
     return BSMR_OK;
+}
+
+// The second, grouped dense format of a tunable plan, packed on demand from the dense entry lists: the RPHM's dense arrays
+// are rebuilt from them (columns of a panel in id order, 16 to a block - the order the packer gives them anyway), the residue
+// left out (it belongs to the first format's plan), and the host packer runs with four panels per group.
+int ensureGrouped(bsmr_plan* p) {
+    if (!p->groupedDeferred || p->fmt[1].H) return BSMR_OK;
+    p->groupedDeferred = false;   // (one attempt)
+    const bsmr::HostDense& hd = p->hostDense;
+    const uint32_t P = hd.numPanels;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    std::vector<uint32_t> blockOffsets((size_t)P + 1, 0), zeros((size_t)P + 1, 0);
+    for (uint32_t q = 0; q < P; ++q) {
+        uint32_t cols = 0;
+        for (uint64_t e = hd.offsets[q]; e < hd.offsets[q + 1]; ++e) cols += e == hd.offsets[q] || hd.col[e] != hd.col[e - 1];
+        blockOffsets[q + 1] = blockOffsets[q] + (cols + 15u) / 16u;
+    }
+    const uint64_t numBlocks = blockOffsets[P];
+    std::vector<uint32_t> denseCols(numBlocks * 16, p->N), blockValues(numBlocks * 256, kNone);
+    bsmr::parallelByWeight(P, blockOffsets.data(), 256, [&](size_t q0, size_t q1, size_t) {
+        for (size_t q = q0; q < q1; ++q) {
+            uint64_t slot = (uint64_t)blockOffsets[q] * 16;   // next column slot of the panel
+            for (uint64_t e = hd.offsets[q]; e < hd.offsets[q + 1]; ++e) {
+                if (e == hd.offsets[q] || hd.col[e] != hd.col[e - 1]) denseCols[slot++] = hd.col[e];
+                const uint64_t at = slot - 1;
+                blockValues[(at / 16) * 256 + (uint64_t)hd.row[e] * 16 + at % 16] = hd.idx[e];
+            }
+        }
+    });
+    bsmr_rphm_desc d{};
+    d.M = p->M; d.N = p->N; d.nnz = p->nnz;
+    d.num_row_panels = P;
+    d.num_nonzero_rows = (uint32_t)hd.panelRows.size();
+    d.reordered_rows = hd.panelRows.data();
+    d.dense_cols = denseCols.data();
+    d.block_offsets = blockOffsets.data();
+    d.block_values = blockValues.data();
+    d.sparse_value_offsets = zeros.data();
+    uint32_t nothing = 0;
+    d.sparse_values = d.sparse_relative_rows = d.sparse_col_indices = &nothing;
+    bsmr::PackedPlan pk4;
+    int st = bsmr::packPlan(&d, p->groupedOpt, pk4);
+    if (st != BSMR_OK) return st;
+    if (pk4.unionColumns * 4 > p->fmt[0].unionColumns * 3) return BSMR_OK;   // (not worth keeping: the rule of bsmr_plan_create)
+    BSMR_HIP(hipSetDevice(p->device));
+    st = uploadDense(p->fmt[1], pk4, p->indexBytes);
+    p->fmt[1].stageInLds = p->fmt[0].stageInLds;
+    return st;
 }
 
 // Dense format for a call with inner dimension K.
@@ -2522,7 +2574,8 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
         // cases in which it has ever won; for a tunable plan bsmr_plan_tune then measures which of the two serves a (K, mode))
         const uint64_t grouped4 = st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8
                                       ? bsmr::countUnionColumns(d, 4) : 0;
-        if (grouped4 && pk.unionColumns * 2 >= 5 * grouped4 && (promotedOnDevice || denseResident)) {   // (the host packer builds that one: it needs the values)
+        const bool deferGrouped = p->tunable && p->hostDense.entries() != 0 && opt.columnOrder;
+        if (grouped4 && pk.unionColumns * 2 >= 5 * grouped4 && (promotedOnDevice || denseResident) && !deferGrouped) {   // (the host packer builds that one: it needs the values)
             freePlanDevice(p);
             delete p;
             if (res) return kPackOnHost;
@@ -2530,7 +2583,13 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
             again.promote_on_device = 0;
             return bsmr_plan_create_ex(out, device, given, &again);
         }
-        if (grouped4 && pk.unionColumns * 2 >= 5 * grouped4) {
+        if (grouped4 && pk.unionColumns * 2 >= 5 * grouped4 && deferGrouped) {
+            // (a tunable plan: the format is packed from the entry lists the first time bsmr_plan_tune wants to measure it)
+            p->groupedDeferred = true;
+            p->groupedOpt = opt;
+            p->groupedOpt.group = 4;
+            p->groupedOpt.blocksPerItem = o.dense_blocks_per_item > 0 ? o.dense_blocks_per_item : 32;
+        } else if (grouped4 && pk.unionColumns * 2 >= 5 * grouped4) {
             bsmr::PackedPlan pk4;
             opt.group = 4;
             opt.blocksPerItem = o.dense_blocks_per_item > 0 ? o.dense_blocks_per_item : 32;
@@ -2957,6 +3016,9 @@ int tuneEngines(bsmr_plan* plan, uint32_t K, const float* A, const float* B, flo
     //    over the group sizes and work-item lengths it serves at this K
     if (lowp && plan->fmt[0].numItems && !plan->convertInKernel) {
         std::vector<bsmr_plan::Tuned> candidates = {{BSMR_ENGINE_STREAM, 0, 0, 0}};
+        // (the grouped format of a tunable plan is packed now if this call could use it: where the GEMM engine is a candidate
+        // it has been 2x faster than the grouped streaming kernel on every pattern measured, and the format is left out)
+        if (plan->groupedDeferred && !(sweepApplies(plan) && gemmServesK(K) && gemmFits(plan, K)) && (st = ensureGrouped(plan)) != BSMR_OK) return st;
         if (plan->fmt[1].H) candidates.push_back({BSMR_ENGINE_STREAM, 0, 0, 1});
         if (plan->hostDense.entries() != 0 && tilesServeK(K)) {
             candidates.push_back({BSMR_ENGINE_TILES, 0, 0});
@@ -3215,6 +3277,11 @@ int bsmr_plan_set_tuned(bsmr_plan* plan, uint32_t K, int mode, const bsmr_tuned_
     if (!engineOk || t.group < 0 || t.blocksPerItem < 0 || t.format < -1 || t.format > 1 || t.bOnly < -1 || t.bOnly > 1 ||
         t.overlap < -1 || t.overlap > 1 || t.cvt < -1 || t.cvt > 1 || t.waves < 0)
         return BSMR_ERR_INVALID_ARG;
+    if (t.format == 1 && !plan->fmt[1].H && plan->groupedDeferred) {
+        BSMR_HIP(hipSetDevice(plan->device));
+        const int gs = ensureGrouped(plan);
+        if (gs != BSMR_OK) return gs;
+    }
     if (t.format == 1 && !plan->fmt[1].H) return BSMR_ERR_BAD_PLAN;
     if ((t.engine == BSMR_ENGINE_TILES || t.engine == BSMR_ENGINE_SHARED) && (!tilesServeK(K) || plan->hostDense.entries() == 0)) return BSMR_ERR_BAD_PLAN;
     if (t.engine == BSMR_ENGINE_SWEEP && (!sweepServesK(K) || plan->hostDense.entries() == 0)) return BSMR_ERR_BAD_PLAN;

@@ -352,3 +352,45 @@ def test_plan_from_the_device_arrays_of_the_column_reordering(engine, oracle, na
         for plan in plans.values():
             engine.plan_destroy(plan)
         hip.bsmr_col_reorder_free(h)
+
+
+def test_grouped_format_of_a_tunable_plan_is_packed_on_demand(engine, oracle):
+    """A plan's second, grouped format (4 panels per group) costs the host packer as much as the first.  A tunable plan
+    leaves it out at creation and packs it from its dense entry lists when bsmr_plan_tune first meets a call that could use
+    it - one the GEMM engine does not serve (K = 96 here; at K = 128 the format stays away).  Packed that way it is the
+    format a plan of the default engine builds at creation (same tiles, same union columns), and the tuned call computes."""
+    rows, cols, ro, ci = synth.bernoulli(rows=2048, cols=2048, density=0.1, seed=4)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    arrays = engine.Pipeline(csr, alpha=0.3, delta=0.0, device=-1).arrays()
+    st, rules = engine.plan_from_arrays(rows, cols, csr.nnz, arrays, device=0, options=engine.plan_options())
+    assert st == engine.OK
+    st, tuned = engine.plan_from_arrays(rows, cols, csr.nnz, arrays, device=0, options=engine.plan_options(dense_engine=3))
+    assert st == engine.OK
+    try:
+        def stats(plan):
+            s = engine.PlanStats()
+            assert engine.hip().bsmr_plan_get_stats(plan, s) == engine.OK
+            return s
+        want = stats(rules)
+        assert want.grouped_group_size == 4, "the case must qualify for the grouped format"
+        assert stats(tuned).grouped_group_size == 0
+        dev = torch.device("cuda:0")
+        for K, expect in ((128, 0), (96, 4)):
+            A, B = engine.make_data(rows * K, 5489), engine.make_data(cols * K, 5490)
+            tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+            tP = torch.full((csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+            report = engine.plan_tune(tuned, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
+            got = stats(tuned)
+            assert got.grouped_group_size == expect, (K, report)
+            if expect:
+                assert (got.grouped_dense_tiles, got.grouped_union_columns) == (want.grouped_dense_tiles, want.grouped_union_columns)
+                assert report["grouped_us"] > 0, report
+            tP.fill_(float("nan"))
+            engine.sddmm(tuned, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), engine.COMPUTE_F16, 0)
+            torch.cuda.synchronize()
+            bad, first = oracle.check_data(oracle.sddmm_cpu(rows, cols, K, ro, ci, A, B), tP.cpu().numpy())
+            assert bad == 0, (K, bad, first)
+            print(f"K={K}: chosen {report['chosen']} group {report['group']}, grouped_us {report['grouped_us']}, stream_us {report['stream_us']}")
+    finally:
+        engine.plan_destroy(rules)
+        engine.plan_destroy(tuned)
