@@ -161,6 +161,8 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
     constexpr uint32_t rowTableAt = gemmRingBytes(PM, NB);
     // batches of 64 entry words requested together (fewer where the accumulators leave few registers)
     constexpr uint32_t kGemmWordChunk = m * n > 32u ? 4u : 8u;
+    // how the epilogue dumps the accumulators (below): the 8 x 5 tile blocks of this kernel keep to plain 4-byte stores
+    constexpr bool kPlainDump = m * n > 32u;
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t itemId = xcdContiguous(blockIdx.x, gridDim.x);
@@ -227,7 +229,11 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
 #pragma unroll
         for (uint32_t u = 0; u < kGemmWordChunk; ++u) w[u] = GEMM_LAB_SKIP(4) ? kGemmNoEntry : words[e0 + u * kWave + lane];
     };
-    uint32_t wNext[kGemmWordChunk];
+    // the first words of the passes' lists are requested two passes ahead where the registers allow it (a pass is shorter
+    // than the words' way from HBM: 0.1-0.2 us per launch at 256 x 256; the 8 x 5 tile blocks have no registers left for
+    // it - 3 to 8 spilled, 0.25 us lost - and stay one pass ahead)
+    constexpr bool kDeepWords = Q >= 2u && m * n <= 32u;
+    uint32_t wAhead[2][kGemmWordChunk];
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GEMM_LAB_STAMP(2);
@@ -236,13 +242,19 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
     // pass 0's first entry words: an HBM round trip (they are read once per launch).  A short K loop does not cover it from
     // the top of its last slice, so up to four slices request them before the loop and carry the registers through it.
     constexpr bool kEarlyWords = KT <= 4;
-    if (kEarlyWords) loadWords(myList[0], wNext);
+    if (kEarlyWords) {
+        loadWords(myList[0], wAhead[0]);
+        if (kDeepWords) loadWords(myList[1], wAhead[1]);
+    }
 
 #pragma unroll
     for (uint32_t t = 0; t < (uint32_t)KT; ++t) {
         if (t + 1u < (uint32_t)KT && !GEMM_LAB_SKIP(2))   // slice t + 1 -> the other stage
             gemmStage<ADMAS, BDMAS>(Ab, aBytes, Bb, bBytes, lds + ((t + 1u) & 1u) * stageBytes, bAt, wave, voffA, voffB, (t + 1u) * kGemmRowBytes);
-        if (!kEarlyWords && t + 1u == (uint32_t)KT) loadWords(myList[0], wNext);   // ... a long loop: behind its last slice
+        if (!kEarlyWords && t + 1u == (uint32_t)KT) {   // ... a long loop: behind its last slice
+            loadWords(myList[0], wAhead[0]);
+            if (kDeepWords) loadWords(myList[1], wAhead[1]);
+        }
         const uint8_t* base = lds + (t & 1u) * stageBytes;
 #pragma unroll
         for (uint32_t s = 0; s < KSUB; ++s) {
@@ -287,7 +299,19 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
 #pragma unroll
     for (uint32_t q = 0; q < Q; ++q) {
         if (!GEMM_LAB_SKIP(3)) {
-            if (slabAddr < 0x10000u) {
+            if (kPlainDump) {
+                // (the two forms of the ds_write_addtid dump below, laid out one after the other, cost the 8 x 5 tile blocks of
+                // this kernel 5 to 14 spilled registers - 256 x 320 at K = 512: 21.5 us against 20.3 with one plain 4-byte
+                // store per register, which keeps the slab's layout; denseGemmCvt has the registers)
+#pragma unroll
+                for (uint32_t tp = 0; tp < kGemmPassTiles; ++tp) {
+                    const uint32_t tIdx = q * kGemmPassTiles + tp;
+                    if (tIdx < m * n) {
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; ++j) slab[tp * 256u + j * 64u + lane] = acc[tIdx / n][tIdx % n][j];
+                    }
+                }
+            } else if (slabAddr < 0x10000u) {
 #pragma unroll
                 for (uint32_t tp = 0; tp < kGemmPassTiles; ++tp) {
                     const uint32_t tIdx = q * kGemmPassTiles + tp;
@@ -304,8 +328,12 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
         const uint32_t first = myList[q], last = myList[q + 1u];
         uint32_t w[kGemmWordChunk];
 #pragma unroll
-        for (uint32_t u = 0; u < kGemmWordChunk; ++u) w[u] = wNext[u];
-        if (q + 1u < Q) loadWords(last, wNext);                     // the next pass's first words (lists follow each other)
+        for (uint32_t u = 0; u < kGemmWordChunk; ++u) w[u] = wAhead[q & 1u][u];
+        if (kDeepWords) {
+            if (q + 2u < Q) loadWords(myList[q + 2u], wAhead[q & 1u]);
+        } else if (q + 1u < Q) {
+            loadWords(last, wAhead[(q + 1u) & 1u]);                   // the next pass's first words (lists follow each other)
+        }
         for (uint32_t e = first; e < last; e += kGemmWordChunk * kWave) {
             if (e != first) loadWords(e, w);                         // (a list of more than 512 words: rare)
 #pragma unroll
@@ -445,7 +473,11 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
 #pragma unroll
         for (uint32_t u = 0; u < kGemmWordChunk; ++u) w[u] = GEMM_LAB_SKIP(4) ? kGemmNoEntry : words[e0 + u * kWave + lane];
     };
-    uint32_t wNext[kGemmWordChunk];
+    // the first words of the passes' lists are requested two passes ahead where the registers allow it (a pass is shorter
+    // than the words' way from HBM: 0.1-0.2 us per launch at 256 x 256; the 8 x 5 tile blocks have no registers left for
+    // it - 3 to 8 spilled, 0.25 us lost - and stay one pass ahead)
+    constexpr bool kDeepWords = Q >= 2u && m * n <= 32u;
+    uint32_t wAhead[2][kGemmWordChunk];
 
     // slice 0: landed (my chunks), rounded into H[0], slice 1 requested, H[0] published
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -457,11 +489,17 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
     GEMM_LAB_STAMP(3);
     // pass 0's first entry words (an HBM round trip): a loop of up to four slices requests them here and carries them through
     constexpr bool kEarlyWords = KT <= 4;
-    if (kEarlyWords) loadWords(myList[0], wNext);
+    if (kEarlyWords) {
+        loadWords(myList[0], wAhead[0]);
+        if (kDeepWords) loadWords(myList[1], wAhead[1]);
+    }
 
 #pragma unroll
     for (uint32_t t = 0; t < (uint32_t)KT; ++t) {
-        if (!kEarlyWords && t + 1u == (uint32_t)KT) loadWords(myList[0], wNext);
+        if (!kEarlyWords && t + 1u == (uint32_t)KT) {
+            loadWords(myList[0], wAhead[0]);
+            if (kDeepWords) loadWords(myList[1], wAhead[1]);
+        }
         const uint8_t* base = lds + hAt + (t & 1u) * hBytes;
         u32x4 bf[n];
 #pragma unroll
@@ -517,8 +555,12 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
         const uint32_t first = myList[q], last = myList[q + 1u];
         uint32_t w[kGemmWordChunk];
 #pragma unroll
-        for (uint32_t u = 0; u < kGemmWordChunk; ++u) w[u] = wNext[u];
-        if (q + 1u < Q) loadWords(last, wNext);
+        for (uint32_t u = 0; u < kGemmWordChunk; ++u) w[u] = wAhead[q & 1u][u];
+        if (kDeepWords) {
+            if (q + 2u < Q) loadWords(myList[q + 2u], wAhead[q & 1u]);
+        } else if (q + 1u < Q) {
+            loadWords(last, wAhead[(q + 1u) & 1u]);
+        }
         for (uint32_t e = first; e < last; e += kGemmWordChunk * kWave) {
             if (e != first) loadWords(e, w);
 #pragma unroll
