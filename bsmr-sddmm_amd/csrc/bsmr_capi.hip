@@ -250,15 +250,13 @@ int useDevice(int device) {
     return BSMR_OK;
 }
 
-int copyPageable(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
-
 template <typename T>
 int upload(T*& dst, const std::vector<T>& src, uint64_t& bytes) {
     dst = nullptr;
     if (src.empty()) return BSMR_OK;
     const size_t n = src.size() * sizeof(T);
     if (!hipOk(hipMalloc(reinterpret_cast<void**>(&dst), n), "hipMalloc(plan)")) return BSMR_ERR_OOM;
-    if (const int st = copyPageable(dst, src.data(), n, hipMemcpyHostToDevice, nullptr)) return st;
+    BSMR_HIP(hipMemcpy(dst, src.data(), n, hipMemcpyHostToDevice));
     bytes += n;
     return BSMR_OK;
 }
@@ -312,111 +310,6 @@ struct DeviceBuffers {
         return true;
     }
 };
-
-// Copies between pageable host memory and the device through a small ring of pinned buffers: the runtime's own pageable
-// path stages through one buffer at 3.5 GB/s (22 MB of block values = 6.5 ms of the nips-like plan's 12); here the copy of
-// chunk i + 1 into its pinned buffer runs beside the DMA of chunk i.  Synchronous for the caller (the last DMA is waited for).
-struct PinnedRing {
-    static constexpr size_t kBuffers = 4, kBytes = 1u << 20;
-    uint8_t* buf[kBuffers] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t done[kBuffers] = {nullptr, nullptr, nullptr, nullptr};
-    bool ok = false;
-    PinnedRing() {
-        for (size_t i = 0; i < kBuffers; ++i)
-            if (hipHostMalloc(reinterpret_cast<void**>(&buf[i]), kBytes, hipHostMallocDefault) != hipSuccess ||
-                hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) {
-                (void)hipGetLastError();
-                return;
-            }
-        ok = true;
-    }
-    ~PinnedRing() {
-        for (size_t i = 0; i < kBuffers; ++i) {
-            if (done[i]) (void)hipEventDestroy(done[i]);
-            if (buf[i]) (void)hipHostFree(buf[i]);
-        }
-    }
-    PinnedRing(const PinnedRing&) = delete;
-    PinnedRing& operator=(const PinnedRing&) = delete;
-};
-int copyPageable(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
-    if (bytes == 0) return BSMR_OK;
-    // (from 64 KiB: the runtime's own pageable path costs its first caller in a process ~5 ms of set-up; a plan's copies
-    // below that size do not take it)
-    if (bytes < (64u << 10)) {
-        BSMR_HIP(hipMemcpyAsync(dst, src, bytes, kind, s));
-        BSMR_HIP(hipStreamSynchronize(s));
-        return BSMR_OK;
-    }
-    StageTrace trace;
-    // rings are kept for the life of the process, per device (their events belong to one)
-    static std::mutex poolLock;
-    static std::map<int, std::vector<PinnedRing*>> pool;
-    int device = 0;
-    BSMR_HIP(hipGetDevice(&device));
-    PinnedRing* held = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(poolLock);
-        std::vector<PinnedRing*>& mine = pool[device];
-        if (!mine.empty()) {
-            held = mine.back();
-            mine.pop_back();
-        }
-    }
-    if (!held) held = new (std::nothrow) PinnedRing;
-    struct Return {
-        PinnedRing* r;
-        int device;
-        ~Return() {
-            if (!r) return;
-            if (!r->ok) {
-                delete r;
-                return;
-            }
-            std::lock_guard<std::mutex> lock(poolLock);
-            pool[device].push_back(r);
-        }
-    } giveBack{held, device};
-    if (!held || !held->ok) {
-        BSMR_HIP(hipMemcpyAsync(dst, src, bytes, kind, s));
-        BSMR_HIP(hipStreamSynchronize(s));
-        return BSMR_OK;
-    }
-    PinnedRing& ring = *held;
-    trace.mark("  pageable copy: ring");
-    const size_t chunks = (bytes + PinnedRing::kBytes - 1) / PinnedRing::kBytes;
-    const uint8_t* from = static_cast<const uint8_t*>(src);
-    uint8_t* to = static_cast<uint8_t*>(dst);
-    if (kind == hipMemcpyHostToDevice) {
-        for (size_t c = 0; c < chunks; ++c) {
-            const size_t i = c % PinnedRing::kBuffers, at = c * PinnedRing::kBytes, n = std::min(PinnedRing::kBytes, bytes - at);
-            if (c >= PinnedRing::kBuffers) BSMR_HIP(hipEventSynchronize(ring.done[i]));
-            std::memcpy(ring.buf[i], from + at, n);
-            BSMR_HIP(hipMemcpyAsync(to + at, ring.buf[i], n, hipMemcpyHostToDevice, s));
-            BSMR_HIP(hipEventRecord(ring.done[i], s));
-        }
-        BSMR_HIP(hipStreamSynchronize(s));
-    } else {
-        // device -> host: chunk c's DMA is requested kBuffers - 1 chunks ahead of the copy out of its pinned buffer
-        auto request = [&](size_t c) -> int {
-            const size_t i = c % PinnedRing::kBuffers, at = c * PinnedRing::kBytes, n = std::min(PinnedRing::kBytes, bytes - at);
-            BSMR_HIP(hipMemcpyAsync(ring.buf[i], from + at, n, hipMemcpyDeviceToHost, s));
-            BSMR_HIP(hipEventRecord(ring.done[i], s));
-            return BSMR_OK;
-        };
-        for (size_t c = 0; c < std::min(chunks, PinnedRing::kBuffers - 1); ++c)
-            if (const int st = request(c)) return st;
-        for (size_t c = 0; c < chunks; ++c) {
-            const size_t i = c % PinnedRing::kBuffers, at = c * PinnedRing::kBytes, n = std::min(PinnedRing::kBytes, bytes - at);
-            if (c + PinnedRing::kBuffers - 1 < chunks)
-                if (const int st = request(c + PinnedRing::kBuffers - 1)) return st;
-            BSMR_HIP(hipEventSynchronize(ring.done[i]));
-            std::memcpy(to + at, ring.buf[i], n);
-        }
-    }
-    trace.mark("  pageable copy: chunks");
-    return BSMR_OK;
-}
 
 int envInt(const char* name, int fallback) {
     const char* v = std::getenv(name);
@@ -707,11 +600,9 @@ int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, con
         !dev.alloc(&dFlags, 1, "hipMalloc") || !dev.alloc(&dMaxItem, 1, "hipMalloc") || !dev.alloc(&dCounters, 2, "hipMalloc"))
         return BSMR_ERR_OOM;
     trace.mark("device packer: scratch");
-    if (!resident)
-        if (const int st = copyPageable(dCols, d->dense_cols, slots * 4, hipMemcpyHostToDevice, s)) return st;
+    if (!resident) BSMR_HIP(hipMemcpyAsync(dCols, d->dense_cols, slots * 4, hipMemcpyHostToDevice, s));
     BSMR_HIP(hipMemcpyAsync(dOffsets, d->block_offsets, ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
-    if (!resident)
-        if (const int st = copyPageable(dValues, d->block_values, oldBlocks * 1024, hipMemcpyHostToDevice, s)) return st;
+    if (!resident) BSMR_HIP(hipMemcpyAsync(dValues, d->block_values, oldBlocks * 1024, hipMemcpyHostToDevice, s));
     trace.mark("device packer: upload arrays");
     BSMR_HIP(hipMemsetAsync(dFlags, 0, 4, s));
     BSMR_HIP(hipMemsetAsync(dMaxItem, 0, 4, s));
@@ -847,10 +738,9 @@ int packDenseOnDevice(const bsmr_rphm_desc* d, const bsmr::PackOptions& opt, con
         BSMR_HIP(hipMemcpyAsync(listStart.data(), dBlockStart, ((size_t)numBlocks + 1) * 4, hipMemcpyDeviceToHost, s));
         BSMR_HIP(hipMemcpyAsync(firstBlock.data(), dFirstBlock, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, s));
         if (total) {
-            int cs = copyPageable(collect->col.data(), dListCol, total * 4, hipMemcpyDeviceToHost, s);
-            if (cs == BSMR_OK) cs = copyPageable(collect->idx.data(), dListIdx, total * 4, hipMemcpyDeviceToHost, s);
-            if (cs == BSMR_OK) cs = copyPageable(collect->row.data(), dListRow, total, hipMemcpyDeviceToHost, s);
-            if (cs != BSMR_OK) return cs;
+            BSMR_HIP(hipMemcpyAsync(collect->col.data(), dListCol, total * 4, hipMemcpyDeviceToHost, s));
+            BSMR_HIP(hipMemcpyAsync(collect->idx.data(), dListIdx, total * 4, hipMemcpyDeviceToHost, s));
+            BSMR_HIP(hipMemcpyAsync(collect->row.data(), dListRow, total, hipMemcpyDeviceToHost, s));
         }
         // (waited for with the items' flags below; the panels' offsets follow there)
         trace.mark("device packer: entry lists");
@@ -2076,13 +1966,15 @@ int bsmr_dev_free(void* ptr) {
 int bsmr_memcpy_h2d(void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return BSMR_OK;
     if (!dst || !src) return BSMR_ERR_INVALID_ARG;
-    return copyPageable(dst, src, bytes, hipMemcpyHostToDevice, nullptr);
+    BSMR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return BSMR_OK;
 }
 
 int bsmr_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return BSMR_OK;
     if (!dst || !src) return BSMR_ERR_INVALID_ARG;
-    return copyPageable(dst, src, bytes, hipMemcpyDeviceToHost, nullptr);
+    BSMR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return BSMR_OK;
 }
 
 int bsmr_dev_memset(void* dst, int value, size_t bytes) {
@@ -3424,15 +3316,16 @@ int bsmr_sddmm_host(bsmr_plan* plan, uint32_t K, const float* A_host, const floa
         cleanup();
         return BSMR_ERR_OOM;
     }
-    if (copyPageable(A, A_host, aBytes, hipMemcpyHostToDevice, nullptr) != BSMR_OK ||
-        copyPageable(B, B_host, bBytes, hipMemcpyHostToDevice, nullptr) != BSMR_OK ||
+    if (!hipOk(hipMemcpy(A, A_host, aBytes, hipMemcpyHostToDevice), "h2d A") ||
+        !hipOk(hipMemcpy(B, B_host, bBytes, hipMemcpyHostToDevice), "h2d B") ||
         !hipOk(hipMemset(P, 0, std::max<size_t>(pBytes, 16)), "memset P")) {
         cleanup();
         return BSMR_ERR_HIP;
     }
     bsmr_timing t{};
     st = bsmr_sddmm_timed(plan, K, A, B, P, mode, nullptr, 1, iters, &t);
-    if (st == BSMR_OK && pBytes) st = copyPageable(P_host, P, pBytes, hipMemcpyDeviceToHost, nullptr);
+    if (st == BSMR_OK && pBytes && !hipOk(hipMemcpy(P_host, P, pBytes, hipMemcpyDeviceToHost), "d2h P"))
+        st = BSMR_ERR_HIP;
     if (st == BSMR_OK && ms_per_iter) *ms_per_iter = t.total_ms;
     cleanup();
     return st;
