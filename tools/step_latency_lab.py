@@ -55,8 +55,15 @@ def burst(n, poll):
 
 
 # the first bursts after the tuner, one by one: what a single timed region (bench.py's) sees
+# (LAB_PRE=n: n more steps and a synchronise in front of them; LAB_SLEEP_MS: a pause)
+for _ in range(int(os.environ.get("LAB_PRE", "0"))):
+    step()
+torch.cuda.synchronize()
+time.sleep(float(os.environ.get("LAB_SLEEP_MS", "0")) / 1e3)
 first = [burst(20, False) for _ in range(6)]
 print("first bursts of 20 after the tuner (wall, enqueue us):", [(round(w, 1), round(e, 1)) for w, e in first], flush=True)
+if os.environ.get("LAB_FIRST_ONLY"):
+    sys.exit(0)
 for poll in (False, True):
     pts = []
     for n in (1, 2, 5, 10, 20, 50, 100, 200):
