@@ -818,6 +818,8 @@ int ensureGrouped(bsmr_plan* p) {
     if (!p->groupedDeferred || p->fmt[1].H) return BSMR_OK;
     p->groupedDeferred = false;   // (one attempt)
     const bsmr::HostDense& hd = p->hostDense;
+    // only where grouping cuts the gathered columns 2.5x (the rule of bsmr_plan_create; counted from the lists, no packing)
+    if (p->fmt[0].unionColumns * 2 < 5 * bsmr::tileCensus(hd, 4).unionColumns) return BSMR_OK;
     const uint32_t P = hd.numPanels;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     std::vector<uint32_t> blockOffsets((size_t)P + 1, 0), zeros((size_t)P + 1, 0);
@@ -2464,9 +2466,10 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
         // (only when it could ever be chosen: chooseFormat wants the ungrouped columns cut 2.5x)
         // (packing it costs as much as the first format did on the host: only where grouping cuts the gathers 2.5x - the
         // cases in which it has ever won; for a tunable plan bsmr_plan_tune then measures which of the two serves a (K, mode))
-        const uint64_t grouped4 = st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8
-                                      ? bsmr::countUnionColumns(d, 4) : 0;
         const bool deferGrouped = p->tunable && p->hostDense.entries() != 0 && opt.columnOrder;
+        const bool groupedPossible = st == BSMR_OK && forcedGroup == 0 && !p->convertInKernel && pk.numBlocks && P >= 8;
+        // (a plan that defers the format also defers the count of the grouped columns: ensureGrouped takes it from the lists)
+        const uint64_t grouped4 = groupedPossible && !deferGrouped ? bsmr::countUnionColumns(d, 4) : 0;
         if (grouped4 && pk.unionColumns * 2 >= 5 * grouped4 && (promotedOnDevice || denseResident) && !deferGrouped) {   // (the host packer builds that one: it needs the values)
             freePlanDevice(p);
             delete p;
@@ -2475,7 +2478,7 @@ int createPlan(bsmr_plan** out, int device, const bsmr_rphm_desc* d, const bsmr_
             again.promote_on_device = 0;
             return bsmr_plan_create_ex(out, device, given, &again);
         }
-        if (grouped4 && pk.unionColumns * 2 >= 5 * grouped4 && deferGrouped) {
+        if (groupedPossible && deferGrouped) {
             // (a tunable plan: the format is packed from the entry lists the first time bsmr_plan_tune wants to measure it)
             p->groupedDeferred = true;
             p->groupedOpt = opt;
