@@ -201,3 +201,63 @@ def test_tuned_choice_can_be_read_and_replayed(engine, oracle):
     assert engine.hip().bsmr_plan_set_tuned(plain, K, mode, C.byref(bad_choice)) == engine.ERR_INVALID_ARG
     for p in (first, second, plain):
         engine.plan_destroy(p)
+
+
+@pytest.mark.parametrize("K,mode,fp32", [(128, 0, 1), (128, 1, 0), (256, 0, 0)])
+def test_gemm_engine_batched_calls_and_graph_replay(engine, oracle, K, mode, fp32):
+    """bsmr_sddmm_batch through the GEMM engine (grid y = the batch; the operand and output strides reach the kernel's
+    LDS-DMA descriptors), on 16-bit copies and on the callers' fp32 operands: every batch equals the single call on its
+    operands bit for bit and meets the oracle.  And the engine inside a captured graph: bsmr_plan_reserve builds the
+    macro-tile format, the captured call allocates nothing, replays recompute P for new operand values."""
+    rows, cols, ro, ci = synth.bernoulli(rows=700, cols=1300, density=0.08, seed=K + mode)
+    csr = engine.CSR.from_arrays(rows, cols, ro, ci)
+    arrays = engine.Pipeline(csr, alpha=0.3, delta=0.0, device=-1).arrays()
+    st, plan = engine.plan_from_arrays(rows, cols, csr.nnz, arrays, device=0,
+                                       options=engine.plan_options(dense_engine=engine.ENGINE_GEMM, gemm_fp32=fp32))
+    assert st == engine.OK
+    try:
+        nb, dev = 3, _dev()
+        A = np.concatenate([engine.make_data(rows * K, 100 + b) for b in range(nb)])
+        B = np.concatenate([engine.make_data(cols * K, 200 + b) for b in range(nb)])
+        tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+        tP = torch.full((nb * csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+        s = torch.cuda.current_stream(dev).cuda_stream
+        engine.sddmm_batch(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), nb, mode, s)
+        torch.cuda.synchronize()
+        got = tP.cpu().numpy().reshape(nb, csr.nnz)
+        assert not np.isnan(got).any()
+        one = torch.full((csr.nnz,), float("nan"), dtype=torch.float32, device=dev)
+        for b in range(nb):
+            a, bb = tA[b * rows * K:(b + 1) * rows * K], tB[b * cols * K:(b + 1) * cols * K]
+            one.fill_(float("nan"))
+            engine.sddmm(plan, K, a.data_ptr(), bb.data_ptr(), one.data_ptr(), mode, s)
+            torch.cuda.synchronize()
+            assert np.array_equal(got[b].view(np.uint32), one.cpu().numpy().view(np.uint32)), f"batch {b}"
+            want = oracle.sddmm_cpu(rows, cols, K, ro, ci, A[b * rows * K:(b + 1) * rows * K], B[b * cols * K:(b + 1) * cols * K])
+            if not (mode == 1 and K < 512):
+                assert oracle.check_data(want, got[b])[0] == 0
+        # captured: the single call on batch 0's operands
+        assert engine.hip().bsmr_plan_reserve(plan, K) == engine.OK
+        side = torch.cuda.Stream(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            engine.sddmm(plan, K, tA.data_ptr(), tB.data_ptr(), one.data_ptr(), mode, side.cuda_stream)
+            side.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                engine.sddmm(plan, K, tA.data_ptr(), tB.data_ptr(), one.data_ptr(), mode, torch.cuda.current_stream(dev).cuda_stream)
+        for _ in range(2):
+            one.fill_(float("nan"))
+            graph.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(one.cpu().numpy().view(np.uint32), got[0].view(np.uint32))
+        tA[:rows * K].copy_(tA[rows * K:2 * rows * K])      # new values behind the same pointers
+        tB[:cols * K].copy_(tB[cols * K:2 * cols * K])
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(one.cpu().numpy().view(np.uint32), got[1].view(np.uint32))
+        import ctypes as C
+        g, t, u = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+        engine.hip().bsmr_plan_dense_choice(plan, K, C.byref(g), C.byref(t), C.byref(u))
+        assert g.value in (8, 16), "the GEMM engine must have served the calls"
+    finally:
+        engine.plan_destroy(plan)
