@@ -33,8 +33,9 @@ sh = torch.cuda.current_stream(dev).cuda_stream
 plan = pipe.plan
 eng.hip().bsmr_plan_reserve(plan, K)
 mode = eng.COMPUTE_F16
+t_tune = time.perf_counter()
 tuned = eng.plan_tune(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), mode, sh)
-print("chosen", tuned["chosen"], tuned["group"], tuned["blocks_per_item"], flush=True)
+print("chosen", tuned["chosen"], tuned["group"], tuned["blocks_per_item"], f"(bsmr_plan_tune took {(time.perf_counter() - t_tune) * 1e3:.0f} ms)", flush=True)
 step = lambda: eng.sddmm(plan, K, tA.data_ptr(), tB.data_ptr(), tP.data_ptr(), mode, sh)
 
 
