@@ -430,32 +430,57 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
 #pragma unroll
     for (uint32_t q = 0; q <= Q; ++q) myList[q] = lists[listBase + wave * Q + q];
 
-    // rounding step: my chunks of F -> stage `to` of H
+    // rounding step: my chunks of F -> stage `to` of H.  The reads of a batch of chunks are issued together, then rounded and
+    // written: written chunk by chunk (read, round, write, read ...) every read waited for the write in front of it - the
+    // compiler cannot know that F and H do not overlap - and a wave paid nine LDS round trips in a row per slice.
+#if defined(BSMR_GEMM_ROUND_SERIAL)
+    constexpr uint32_t kRoundBatch = 1u;      // lab: one chunk at a time
+#else
+    constexpr uint32_t kRoundBatch = 5u;
+#endif
+    // (addresses: a chunk's place in F is one register per operand plus j KiB; its rows' places in H are two registers per
+    // operand - the swizzle of row 8 c + (lane >> 3) depends on c's parity only - plus j * 512 + the stage: nine source and
+    // nine destination registers, live over the whole kernel, were what the 8 x 5 tile blocks had no room for)
+    const uint32_t fOfA = wave * ADMAS * 1024u + lane * 16u, fOfB = bAtF + wave * BDMAS * 1024u + lane * 16u;
+    auto hOf = [&](uint32_t part, uint32_t firstChunk, uint32_t odd) {
+        const uint32_t quarter = (2u * (firstChunk + odd) + (lane >> 5)) & 3u;            // (row >> 2) & 3 of the lane's row
+        return hAt + part + firstChunk * 512u + (lane >> 3) * kGemmHalfRowBytes + (((piece >> 1) ^ ((4u - quarter) & 3u)) << 4) + ((piece & 1u) << 3);
+    };
+    const uint32_t hOfA[2] = {hOf(0u, wave * ADMAS, 0u), hOf(0u, wave * ADMAS, 1u)};
+    const uint32_t hOfB[2] = {hOf(bAtH, wave * BDMAS, 0u), hOf(bAtH, wave * BDMAS, 1u)};
     auto roundChunks = [&](uint32_t to) {
-        uint8_t* H = lds + hAt + to * hBytes;
+        if (GEMM_LAB_SKIP(1)) return;
 #pragma unroll
-        for (uint32_t j = 0; j < DMAS; ++j) {
-            const bool isA = j < ADMAS;
-            const uint32_t chunk = isA ? wave * ADMAS + j : wave * BDMAS + (j - ADMAS);
-            const uint32_t row = 8u * chunk + (lane >> 3);                       // row of A's part / of B's part
-            const uint8_t* src = lds + (isA ? 0u : bAtF) + chunk * 1024u + lane * 16u;
-            uint8_t* dst = H + (isA ? 0u : bAtH) + row * kGemmHalfRowBytes + (((piece >> 1) ^ gemmSwzH(row)) << 4) + ((piece & 1u) << 3);
-            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            if (GEMM_LAB_SKIP(1)) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
-            u32x2 h;
-            if constexpr (MODE == 0) {
-                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-                f16x4 o;
-                o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
-                h = __builtin_bit_cast(u32x2, o);
-            } else {
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                bf16x4 o;
-                o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
-                h = __builtin_bit_cast(u32x2, o);
+        for (uint32_t j0 = 0; j0 < DMAS; j0 += kRoundBatch) {
+            f32x4 v[kRoundBatch];
+#pragma unroll
+            for (uint32_t b = 0; b < kRoundBatch; ++b) {
+                const uint32_t j = j0 + b;
+                if (j >= DMAS) continue;
+                v[b] = j < ADMAS ? *reinterpret_cast<const f32x4*>(lds + fOfA + j * 1024u)
+                                 : *reinterpret_cast<const f32x4*>(lds + fOfB + (j - ADMAS) * 1024u);
             }
-            *reinterpret_cast<u32x2*>(dst) = h;
+#pragma unroll
+            for (uint32_t b = 0; b < kRoundBatch; ++b) {
+                const uint32_t j = j0 + b;
+                if (j >= DMAS) continue;
+                const uint32_t jj = j < ADMAS ? j : j - ADMAS;
+                uint8_t* dst = lds + (j < ADMAS ? hOfA[jj & 1u] : hOfB[jj & 1u]) + jj * 512u + to * hBytes;
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 h;
+                if constexpr (MODE == 0) {
+                    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                    f16x4 o;
+                    o[0] = (_Float16)v[b][0]; o[1] = (_Float16)v[b][1]; o[2] = (_Float16)v[b][2]; o[3] = (_Float16)v[b][3];
+                    h = __builtin_bit_cast(u32x2, o);
+                } else {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 o;
+                    o[0] = (__bf16)v[b][0]; o[1] = (__bf16)v[b][1]; o[2] = (__bf16)v[b][2]; o[3] = (__bf16)v[b][3];
+                    h = __builtin_bit_cast(u32x2, o);
+                }
+                *reinterpret_cast<u32x2*>(dst) = h;
+            }
         }
     };
 
