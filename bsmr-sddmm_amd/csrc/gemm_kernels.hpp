@@ -125,6 +125,17 @@ __device__ __forceinline__ void gemmStagePart(const uint8_t* src, uint32_t srcBy
     for (uint32_t j = 0; j < DMAS; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (wave * DMAS + j) * 1024u), 16, voff[j], kOff, 0, 0);
 }
+// The epilogue's store of one entry: a buffer store whose byte offset is out of range for the lanes without an entry (the
+// hardware drops those), so that the pass is straight-line code.  Under `if (entry) P[dst] = val` every batch of 64 entries
+// was a branch around a store: the compiler could not count the stores between a batch of entry words and its use any
+// more, waited with vmcnt(2), (1), (0) for words that had landed long before - and with them for the acknowledgements of
+// the stores issued in between (stores and loads share the counter on gfx9).
+#if !defined(BSMR_GEMM_BRANCHY_STORES)
+__device__ __forceinline__ void gemmStoreEntry(float* P, bool live, uint32_t index, float val) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(P, 0, 0xFFFFFFFC, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), rsrc, live ? index << 2 : 0xFFFFFFFFu, 0, 0);
+}
+#endif
 template <uint32_t ADMAS, uint32_t BDMAS>
 __device__ __forceinline__ void gemmStage(const uint8_t* A, uint32_t aBytes, const uint8_t* B, uint32_t bBytes, uint8_t* stage, uint32_t bAt,
                                           uint32_t wave, const uint32_t* voffA, const uint32_t* voffB, uint32_t kOff) {
@@ -338,11 +349,19 @@ denseGemm(const void* __restrict__ Aop, const void* __restrict__ Bop, uint32_t a
             if (e != first) loadWords(e, w);                         // (a list of more than 512 words: rare)
 #pragma unroll
             for (uint32_t u = 0; u < kGemmWordChunk; ++u) {
+#if defined(BSMR_GEMM_BRANCHY_STORES)   // lab: the form with a branch per batch
                 if (e + u * kWave + lane < last && w[u] != kGemmNoEntry) {
                     const float val = slab[w[u] & 4095u];
                     const uint32_t dst = rowTable[(w[u] >> 12) & 127u] + (w[u] >> 19);
                     if (!GEMM_LAB_SKIP(5)) P[dst] = val;
                 }
+#else
+                // (a padding word reads slot 4095 and row TM / 2 - 1: inside the slab and the table)
+                const bool live = e + u * kWave + lane < last && w[u] != kGemmNoEntry;
+                const float val = slab[w[u] & 4095u];
+                const uint32_t dst = rowTable[(w[u] >> 12) & (TM / 2u - 1u)] + (w[u] >> 19);
+                if (!GEMM_LAB_SKIP(5)) gemmStoreEntry(P, live, dst, val);
+#endif
             }
         }
         GEMM_LAB_STAMP(5u + q);
@@ -590,11 +609,19 @@ denseGemmCvt(const float* __restrict__ Aop, const float* __restrict__ Bop, uint3
             if (e != first) loadWords(e, w);
 #pragma unroll
             for (uint32_t u = 0; u < kGemmWordChunk; ++u) {
+#if defined(BSMR_GEMM_BRANCHY_STORES)   // lab: the form with a branch per batch
                 if (e + u * kWave + lane < last && w[u] != kGemmNoEntry) {
                     const float val = slab[w[u] & 4095u];
                     const uint32_t dst = rowTable[(w[u] >> 12) & 127u] + (w[u] >> 19);
                     if (!GEMM_LAB_SKIP(5)) P[dst] = val;
                 }
+#else
+                // (a padding word reads slot 4095 and row TM / 2 - 1: inside the slab and the table)
+                const bool live = e + u * kWave + lane < last && w[u] != kGemmNoEntry;
+                const float val = slab[w[u] & 4095u];
+                const uint32_t dst = rowTable[(w[u] >> 12) & (TM / 2u - 1u)] + (w[u] >> 19);
+                if (!GEMM_LAB_SKIP(5)) gemmStoreEntry(P, live, dst, val);
+#endif
             }
         }
         GEMM_LAB_STAMP(5u + q);
